@@ -1,0 +1,55 @@
+"""Builds ganet_amd/libganet_hip.so (gfx950) from ganet_amd/csrc/*.hip with hipcc.
+
+In-tree build: the .so sits next to this file, is git-ignored and travels to the
+GPU box with the source snapshot.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libganet_hip.so")
+OBJ_DIR = os.path.join(HERE, "csrc", "build")
+
+ARCH = "gfx950"
+COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17",
+          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+          "-Wall", "-Wno-unused-function"]
+# decode.hip must round like numpy / CPython: no fused multiply-add contraction.
+PER_FILE = {"decode.hip": ["-ffp-contract=off"]}
+SOURCES = ["api.hip", "decode.hip", "deform_conv.hip"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build_lib(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(ROOT, "include", "ganet_hip.h"),
+               os.path.join(CSRC, "common.h")]
+    objs, relink = [], force or not os.path.exists(LIB)
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(h, o) for h in headers):
+            cmd = [hipcc] + COMMON + PER_FILE.get(src, []) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            relink = True
+    if relink:
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv, verbose=True)
+    print(LIB)

@@ -1,0 +1,432 @@
+// Keypoint decode + lane grouping for gfx950 (MI355X), hand-written HIP.
+//
+// Restates, for a whole batch per call,
+//   GANetHeadFast.ktdet_decode_fast  mmdet/models/dense_heads/ganet_head.py:203-238
+//   group_points_fast                tools/ganet/post_process.py:141-194
+//
+// Two kernels:
+//   decode_mask_kernel   grid (ceil(HW/256), B): 1x3 NMS + threshold, one pixel per
+//                        lane, one 64-pixel word of the keypoint bitmap per wavefront
+//                        ballot.  Reads the heat plane once, coalesced.
+//   decode_group_kernel  one 256-thread workgroup per image: ordered (row-major)
+//                        compaction of the bitmap by popcount + block scan, sparse
+//                        gathers of offset/error at the keypoints, centre list sorted
+//                        x-major by a rank sort in LDS, greedy centre clustering on one
+//                        wavefront (order dependent, so serial over centres, lane
+//                        parallel over earlier centres), integer means, and the
+//                        first-match keypoint -> centre assignment in float64.
+//
+// Bit-exactness notes (all arithmetic below is IEEE, file built with
+// -ffp-contract=off, no fast-math):
+//   * thresholds are compared in float32 like torch does for Python scalars;
+//   * distances use float64 sub / mul / add / sqrt (correctly rounded on CDNA4);
+//     the reference squares with libm pow(x, 2.0), which is 1 ulp off x*x for a
+//     fraction of a percent of inexact squares - a decision can differ only when a
+//     distance lies within an ulp of the threshold without being exact
+//     (tests/test_oracle_golden.py::test_square_vs_libm_pow);
+//   * the cluster mean is int64-sum / count in float64, truncated, like
+//     np.mean(..., dtype=int).
+
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kMaxCenters = GANET_DECODE_MAX_CENTERS;  // LDS-resident centre list
+constexpr int kLdsGid = 8192;  // keypoint group ids kept in LDS (no-centre mode)
+
+// heat * (max_pool2d(heat,(1,3),1,(0,1)) == heat)   ganet_head.py:205-208.
+// ATen's pool starts at -inf and takes v when (v > max) || isnan(v).
+__device__ __forceinline__ float heat_nms(const float *__restrict__ row, int W,
+                                          int x) {
+  const float h = row[x];
+  float m = -INFINITY;
+  if (x > 0) {
+    const float v = row[x - 1];
+    if (v > m || v != v) m = v;
+  }
+  if (h > m || h != h) m = h;
+  if (x < W - 1) {
+    const float v = row[x + 1];
+    if (v > m || v != v) m = v;
+  }
+  const float keep = (m == h) ? 1.0f : 0.0f;
+  return h * keep;
+}
+
+__global__ __launch_bounds__(kBlock) void decode_mask_kernel(
+    const float *__restrict__ heat, int HW, int W, float thr,
+    unsigned long long *__restrict__ kmask, int nwords) {
+  const int b = blockIdx.y;
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  bool is_kpt = false;
+  if (idx < HW) {
+    const int y = idx / W;
+    const int x = idx - y * W;
+    is_kpt = heat_nms(heat + (size_t)b * HW + (size_t)y * W, W, x) > thr;
+  }
+  const unsigned long long m = __ballot(is_kpt);
+  const int word = idx >> 6;
+  if ((threadIdx.x & 63) == 0 && word < nwords)
+    kmask[(size_t)b * nwords + word] = m;
+}
+
+// Exclusive scan of one int per thread over the 256-thread block.
+__device__ __forceinline__ int block_excl_scan(int v, int *wave_sums,
+                                               int *total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_sums[wid] = incl;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWavesPerBlock; ++w) {
+    const int s = wave_sums[w];
+    if (w < wid) off += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return off + incl - v;
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+
+struct DecodeArgs {
+  const float *heat, *offset, *error;
+  const unsigned long long *kmask;
+  int H, W, nwords;
+  float root_thr;
+  double cluster_thr, by_center_thr;
+  int max_kpts, max_centers, max_groups, flags;
+  ganet_decode_out out;
+};
+
+// DECODE: build the keypoint / centre lists from the bitmap (steps 1-2).
+// !DECODE: the lists already sit in the output arrays (ganet_group_batch).
+template <bool DECODE>
+__global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
+  // One LDS carve-up for both grouping modes (48 KiB).
+  __shared__ int smem[6 * kMaxCenters];
+  __shared__ int wave_sums[kWavesPerBlock];
+  __shared__ int s_nc, s_ng;
+
+  unsigned int *ckey_raw = reinterpret_cast<unsigned int *>(smem);  // unsorted keys
+  unsigned int *ckey = ckey_raw + kMaxCenters;                      // x-major keys
+  volatile int *cgid = smem + 2 * kMaxCenters;
+  int *gsumx = smem + 3 * kMaxCenters;
+  int *gsumy = smem + 4 * kMaxCenters;
+  int *gcnt = smem + 5 * kMaxCenters;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int H = a.H, W = a.W;
+  const size_t HW = (size_t)H * W;
+  const float *off_x = a.offset + (size_t)b * 2 * HW;
+  const float *off_y = off_x + HW;
+  const float *err_x = a.error + (size_t)b * 2 * HW;
+  const float *err_y = err_x + HW;
+  const unsigned long long *kmask = a.kmask + (size_t)b * a.nwords;
+
+  int32_t *o_counts = a.out.counts + (size_t)b * GANET_DECODE_COUNT_STRIDE;
+  int32_t *o_cxy = a.out.centers_xy + (size_t)b * a.max_centers * 2;
+  int32_t *o_cgid = a.out.center_gid + (size_t)b * a.max_centers;
+  int32_t *o_kxy = a.out.kpt_xy + (size_t)b * a.max_kpts * 2;
+  float *o_align = a.out.kpt_align + (size_t)b * a.max_kpts * 2;
+  float *o_root = a.out.kpt_root + (size_t)b * a.max_kpts * 2;
+  int32_t *o_kgid = a.out.kpt_gid + (size_t)b * a.max_kpts;
+  int32_t *o_gc = a.out.group_center + (size_t)b * a.max_groups * 2;
+  int32_t *o_gn = a.out.group_count + (size_t)b * a.max_groups;
+
+  if (tid == 0) {
+    s_nc = 0;
+    s_ng = 0;
+  }
+  __syncthreads();
+
+  int nk = 0, nc_found = 0, nk_st = 0, nc = 0, overflow = 0;
+  if constexpr (DECODE) {
+  // ---- 1. ordered compaction of keypoints (row-major) ---------------------
+  for (int w0 = 0; w0 < a.nwords; w0 += kBlock) {
+    const int w = w0 + tid;
+    unsigned long long bits = (w < a.nwords) ? kmask[w] : 0ull;
+    int total;
+    int pos = nk + block_excl_scan(__popcll(bits), wave_sums, &total);
+    nk += total;
+    while (bits) {
+      const int bit = __ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      const int idx = w * 64 + bit;
+      const int y = idx / W, x = idx - y * W;
+      const float oy = off_y[idx];
+      if (pos < a.max_kpts) {
+        const float fx = (float)x, fy = (float)y;
+        o_kxy[2 * pos] = x;
+        o_kxy[2 * pos + 1] = y;
+        o_root[2 * pos] = fx + off_x[idx];      // ganet_head.py:229
+        o_root[2 * pos + 1] = fy + oy;
+        o_align[2 * pos] = fx + err_x[idx];     // ganet_head.py:230
+        o_align[2 * pos + 1] = fy + err_y[idx];
+        o_kgid[pos] = -1;
+      }
+      // centre: offset_y < root_thr on a keypoint  (ganet_head.py:213-216)
+      if (oy < a.root_thr) {
+        const int slot = atomicAdd(&s_nc, 1);
+        if (slot < kMaxCenters)
+          ckey_raw[slot] = ((unsigned int)x << 16) | (unsigned int)y;
+      }
+      ++pos;
+    }
+  }
+  __syncthreads();
+  nc_found = s_nc;
+  nk_st = min(nk, a.max_kpts);
+  nc = min(nc_found, min(a.max_centers, kMaxCenters));
+  overflow = (nk > a.max_kpts ? 1 : 0) |
+             (nc_found > min(a.max_centers, kMaxCenters) ? 2 : 0);
+
+  // ---- 2. centres in x-major order: rank sort on (x, y) -------------------
+  // (the reference transposes the mask to [W,H] before np.where,
+  //  ganet_head.py:217-219).  Keys are distinct pixels, so ranks are unique.
+  const int nc_sort = min(nc_found, kMaxCenters);
+  for (int i = tid; i < nc_sort; i += kBlock) {
+    const unsigned int ki = ckey_raw[i];
+    int rank = 0;
+    for (int j = 0; j < nc_sort; ++j) rank += (ckey_raw[j] < ki);
+    ckey[rank] = ki;
+  }
+  __syncthreads();
+  for (int i = tid; i < nc; i += kBlock) {
+    o_cxy[2 * i] = (int)(ckey[i] >> 16);
+    o_cxy[2 * i + 1] = (int)(ckey[i] & 0xffffu);
+  }
+
+  } else {
+    nk = o_counts[0];
+    nc_found = o_counts[1];
+    overflow = o_counts[3] & 3;
+    nk_st = min(nk, a.max_kpts);
+    nc = min(nc_found, min(a.max_centers, kMaxCenters));
+    for (int i = tid; i < nc; i += kBlock)
+      ckey[i] = ((unsigned int)o_cxy[2 * i] << 16) | (unsigned int)o_cxy[2 * i + 1];
+    __syncthreads();
+  }
+  int ng = 0;
+  if (a.flags & 1) {
+    // decode only
+  } else if (a.by_center_thr >= 0) {
+    // ---- 3. greedy clustering of the centres (post_process.py:160-165) ----
+    // search_groups returns the first group holding ANY member within thr,
+    // i.e. the smallest group index among earlier centres within thr.
+    const double T = a.by_center_thr;
+    if (wid == 0) {
+      int ngl = 0;
+      for (int i = 0; i < nc; ++i) {
+        const unsigned int ki = ckey[i];
+        const int xi = (int)(ki >> 16), yi = (int)(ki & 0xffffu);
+        int best = INT_MAX;
+        for (int j = lane; j < i; j += 64) {
+          const unsigned int kj = ckey[j];
+          const double dx = (double)(xi - (int)(kj >> 16));
+          const double dy = (double)(yi - (int)(kj & 0xffffu));
+          const double d = sqrt(dx * dx + dy * dy);  // exact integer operand
+          if (d <= T) best = min(best, (int)cgid[j]);
+        }
+        best = wave_min(best);
+        const int g = (best == INT_MAX) ? ngl++ : best;
+        if (lane == 0) cgid[i] = g;
+      }
+      if (lane == 0) s_ng = ngl;
+    }
+    __syncthreads();
+    ng = s_ng;
+    // ---- 4. truncated integer mean per group (post_process.py:38-41) ------
+    for (int g = tid; g < ng; g += kBlock) {
+      gsumx[g] = 0;
+      gsumy[g] = 0;
+      gcnt[g] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < nc; i += kBlock) {
+      const int g = cgid[i];
+      atomicAdd(&gsumx[g], (int)(ckey[i] >> 16));
+      atomicAdd(&gsumy[g], (int)(ckey[i] & 0xffffu));
+      atomicAdd(&gcnt[g], 1);
+      o_cgid[i] = g;
+    }
+    __syncthreads();
+    for (int g = tid; g < ng; g += kBlock) {
+      const double c = (double)gcnt[g];
+      const int mx = (int)(long long)((double)gsumx[g] / c);
+      const int my = (int)(long long)((double)gsumy[g] / c);
+      gsumx[g] = mx;
+      gsumy[g] = my;
+      gcnt[g] = 0;
+      if (g < a.max_groups) {
+        o_gc[2 * g] = mx;
+        o_gc[2 * g + 1] = my;
+      }
+    }
+    __syncthreads();
+    // ---- 5. keypoint -> first centre within thr (post_process.py:61-66,173-179)
+    for (int i = tid; i < nk_st; i += kBlock) {
+      const double rx = (double)o_root[2 * i], ry = (double)o_root[2 * i + 1];
+      int found = -1;
+      for (int g = 0; g < ng; ++g) {
+        const double dx = rx - (double)gsumx[g];
+        const double dy = ry - (double)gsumy[g];
+        const double d = sqrt(dx * dx + dy * dy);
+        if (d <= T) {
+          found = g;
+          break;
+        }
+      }
+      o_kgid[i] = found;
+      if (found >= 0) atomicAdd(&gcnt[found], 1);
+    }
+    __syncthreads();
+    for (int g = tid; g < min(ng, a.max_groups); g += kBlock) o_gn[g] = gcnt[g];
+  } else {
+    // ---- no centre clustering: update_coords_fast (post_process.py:142-153)
+    // Greedy over keypoints in order; group ids live in LDS while they fit,
+    // else in the (workgroup-coherent) output array.
+    const double T = a.cluster_thr;
+    __syncthreads();  // o_root written above by the whole block
+    const bool in_lds = nk_st <= kLdsGid;
+    volatile int *kg = in_lds ? (volatile int *)smem : (volatile int *)o_kgid;
+    if (wid == 0) {
+      int ngl = 0;
+      for (int i = 0; i < nk_st; ++i) {
+        const double rx = (double)o_root[2 * i], ry = (double)o_root[2 * i + 1];
+        int best = INT_MAX;
+        for (int j = lane; j < i; j += 64) {
+          const double dx = rx - (double)o_root[2 * j];
+          const double dy = ry - (double)o_root[2 * j + 1];
+          const double d = sqrt(dx * dx + dy * dy);
+          if (d <= T) best = min(best, (int)kg[j]);
+        }
+        best = wave_min(best);
+        const int g = (best == INT_MAX) ? ngl++ : best;
+        if (lane == 0) kg[i] = g;
+        if (!in_lds) __threadfence_block();
+      }
+      if (lane == 0) s_ng = ngl;
+    }
+    __syncthreads();
+    ng = s_ng;
+    for (int g = tid; g < min(ng, a.max_groups); g += kBlock) o_gn[g] = 0;
+    __syncthreads();
+    for (int i = tid; i < nk_st; i += kBlock) {
+      const int g = kg[i];
+      if (in_lds) o_kgid[i] = g;
+      if (g < a.max_groups) atomicAdd(&o_gn[g], 1);
+    }
+  }
+  if (ng > a.max_groups) overflow |= 4;
+  if (tid == 0) {
+    o_counts[0] = nk;
+    o_counts[1] = nc_found;
+    o_counts[2] = ng;
+    o_counts[3] = overflow;
+    o_counts[4] = 0;
+    o_counts[5] = 0;
+    o_counts[6] = 0;
+    o_counts[7] = 0;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t ganet_decode_workspace_bytes(const ganet_decode_params *p) {
+  if (!p || p->B <= 0 || p->H <= 0 || p->W <= 0) return 0;
+  const size_t nwords = ((size_t)p->H * p->W + 63) / 64;
+  return ganet_align_up((size_t)p->B * nwords * sizeof(unsigned long long), 256);
+}
+
+extern "C" int ganet_decode_batch(const float *heat, const float *offset,
+                                  const float *error,
+                                  const ganet_decode_params *p,
+                                  const ganet_decode_out *out, void *workspace,
+                                  size_t workspace_bytes,
+                                  ganet_stream_t stream) {
+  if (!heat || !offset || !error || !p || !out || !workspace)
+    return GANET_ERR_NULL;
+  if (!out->counts || !out->centers_xy || !out->center_gid || !out->kpt_xy ||
+      !out->kpt_align || !out->kpt_root || !out->kpt_gid ||
+      !out->group_center || !out->group_count)
+    return GANET_ERR_NULL;
+  if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->max_kpts <= 0 ||
+      p->max_centers <= 0 || p->max_groups <= 0)
+    return GANET_ERR_BAD_SHAPE;
+  if (p->H > 65535 || p->W > 65535 ||
+      (long long)p->H * p->W > (long long)INT32_MAX - 4096)
+    return GANET_ERR_UNSUPPORTED;
+  if (p->max_centers > kMaxCenters) return GANET_ERR_UNSUPPORTED;
+  if (p->B > 65535) return GANET_ERR_UNSUPPORTED;  // grid.y of the mask kernel
+  if (workspace_bytes < ganet_decode_workspace_bytes(p))
+    return GANET_ERR_WORKSPACE;
+
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = p->H * p->W;
+  const int nwords = (HW + 63) / 64;
+  unsigned long long *kmask = static_cast<unsigned long long *>(workspace);
+
+  dim3 g1((HW + kBlock - 1) / kBlock, p->B);
+  hipLaunchKernelGGL(decode_mask_kernel, g1, dim3(kBlock), 0, s, heat, HW,
+                     p->W, p->kpt_thr, kmask, nwords);
+  if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+
+  DecodeArgs a;
+  a.heat = heat;
+  a.offset = offset;
+  a.error = error;
+  a.kmask = kmask;
+  a.H = p->H;
+  a.W = p->W;
+  a.nwords = nwords;
+  a.root_thr = p->root_thr;
+  a.cluster_thr = p->cluster_thr;
+  a.by_center_thr = p->by_center_thr;
+  a.max_kpts = p->max_kpts;
+  a.max_centers = p->max_centers;
+  a.max_groups = p->max_groups;
+  a.flags = p->flags;
+  a.out = *out;
+  hipLaunchKernelGGL(decode_group_kernel<true>, dim3(p->B), dim3(kBlock), 0, s, a);
+  return ganet_check_launch();
+}
+
+extern "C" int ganet_group_batch(const ganet_decode_params *p,
+                                 const ganet_decode_out *out,
+                                 ganet_stream_t stream) {
+  if (!p || !out) return GANET_ERR_NULL;
+  if (!out->counts || !out->centers_xy || !out->center_gid || !out->kpt_root ||
+      !out->kpt_gid || !out->group_center || !out->group_count)
+    return GANET_ERR_NULL;
+  if (p->B <= 0 || p->max_kpts <= 0 || p->max_centers <= 0 || p->max_groups <= 0)
+    return GANET_ERR_BAD_SHAPE;
+  if (p->max_centers > kMaxCenters) return GANET_ERR_UNSUPPORTED;
+  DecodeArgs a = {};
+  a.H = p->H;
+  a.W = p->W;
+  a.cluster_thr = p->cluster_thr;
+  a.by_center_thr = p->by_center_thr;
+  a.max_kpts = p->max_kpts;
+  a.max_centers = p->max_centers;
+  a.max_groups = p->max_groups;
+  a.flags = p->flags & ~1;
+  a.out = *out;
+  hipLaunchKernelGGL(decode_group_kernel<false>, dim3(p->B), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return ganet_check_launch();
+}

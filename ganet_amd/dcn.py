@@ -1,0 +1,448 @@
+"""Host-side mirror of the reference's deformable-convolution module API
+(mmdet/ops/dcn/deform_conv.py) on top of the gfx950 C-ABI.
+
+Same names, constructor arguments, parameter names/shapes, state-dict keys and
+exception behaviour as the reference:
+  DeformConvFunction / deform_conv        deform_conv.py:15-111, 187
+  ModulatedDeformConvFunction / modulated_deform_conv   :114-184, 188
+  DeformConv :191-253, DeformConv1D :255-317, DeformConvPack :320-387
+  ModulatedDeformConv :390-437, ModulatedDeformConvPack :440-512
+The forward runs the fused HIP kernel (csrc/deform_conv.hip); there is no
+eager / CPU fallback.  Backward is not built yet (inference path): it raises.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.nn.modules.utils import _pair, _single
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.GANET_F32, torch.bfloat16: _lib.GANET_BF16,
+           torch.float16: _lib.GANET_F16}
+
+
+class _Config(object):
+    """mfma_bf16: contract float32 inputs on the bf16 matrix cores (fp32
+    accumulate, ~1e-2 relative error) instead of the exact-fp32 MFMA."""
+    mfma_bf16 = False
+
+
+config = _Config()
+
+
+def _is_channels_last(t):
+    return (t.dim() == 4 and not t.is_contiguous()
+            and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
+                        dilation=(1, 1), groups=1, deformable_groups=1,
+                        mask=None, bias=None, fuse_relu=False,
+                        offset_is_points=False, mfma_bf16=None):
+    """Raw forward on the HIP library.  `input` NCHW (contiguous or
+    channels_last) on a GPU; returns a tensor of the same memory format."""
+    if not input.is_cuda:
+        raise NotImplementedError
+    if input.dtype not in _DTYPES:
+        raise TypeError("deform_conv: unsupported dtype %s" % input.dtype)
+    L = _lib.lib()
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    nhwc = _is_channels_last(input)
+    if not nhwc:
+        input = input.contiguous()
+    weight = weight.contiguous()
+    if weight.dtype != input.dtype:
+        weight = weight.to(input.dtype)
+    offset = offset.contiguous()
+    if offset.dtype != torch.float32:
+        offset = offset.float()
+    if mask is not None:
+        mask = mask.contiguous()
+        if mask.dtype != torch.float32:
+            mask = mask.float()
+    if bias is not None:
+        bias = bias.contiguous().to(input.dtype)
+    B, Cin, H, W = input.shape
+    Cout, _, kH, kW = weight.shape
+    p = _lib.DcnParams()
+    p.B, p.Cin, p.H, p.W, p.Cout = B, Cin, H, W, Cout
+    p.kH, p.kW = kH, kW
+    p.sH, p.sW = stride
+    p.pH, p.pW = padding
+    p.dH, p.dW = dilation
+    p.groups, p.deformable_groups = groups, deformable_groups
+    p.dtype = _DTYPES[input.dtype]
+    p.x_layout = _lib.GANET_NHWC if nhwc else _lib.GANET_NCHW
+    p.out_layout = p.x_layout
+    use_bf16 = config.mfma_bf16 if mfma_bf16 is None else mfma_bf16
+    p.mfma_bf16 = 1 if (use_bf16 and input.dtype == torch.float32) else 0
+    p.fuse_relu = 1 if fuse_relu else 0
+    p.offset_is_points = 1 if offset_is_points else 0
+    Ho = L.ganet_dcn_out_size(H, p.pH, p.dH, kH, p.sH)
+    Wo = L.ganet_dcn_out_size(W, p.pW, p.dW, kW, p.sW)
+    if Ho < 1 or Wo < 1:
+        raise ValueError("convolution input is too small (output would be "
+                         "%dx%dx%dx%d)" % (B, Cout, Ho, Wo))
+    if weight.shape[1] * groups != Cin:
+        raise RuntimeError("invalid number of input planes, expected: %d, but got: %d"
+                           % (weight.shape[1] * groups, Cin))
+    if tuple(offset.shape) != (B, deformable_groups * 2 * kH * kW, Ho, Wo):
+        if offset.shape[0] != B:
+            raise RuntimeError("invalid batch size of offset")
+        if offset.shape[1] != deformable_groups * 2 * kH * kW:
+            raise RuntimeError("invalid number of channels of offset")
+        raise RuntimeError(
+            "invalid spatial size of offset, expected height: %d width: %d, but "
+            "got height: %d width: %d" % (Ho, Wo, offset.shape[2], offset.shape[3]))
+    if mask is not None and tuple(mask.shape) != (B, deformable_groups * kH * kW, Ho, Wo):
+        raise RuntimeError("invalid shape of mask")
+    out = torch.empty((B, Cout, Ho, Wo), dtype=input.dtype, device=input.device,
+                      memory_format=torch.channels_last if nhwc
+                      else torch.contiguous_format)
+    ws_bytes = L.ganet_deform_conv_workspace_bytes(ctypes.byref(p))
+    if ws_bytes == 0:
+        # let the library name the reason
+        ws_bytes = 256
+    with torch.cuda.device(input.device):
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
+        stream = torch.cuda.current_stream(input.device).cuda_stream
+        rc = L.ganet_deform_conv_forward(
+            input.data_ptr(), offset.data_ptr(),
+            mask.data_ptr() if mask is not None else None, weight.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out.data_ptr(),
+            ctypes.byref(p), ws.data_ptr(), ws_bytes, stream)
+    if rc == _lib.GANET_ERR_BAD_SHAPE and mask is None and (H < kH or W < kW):
+        raise RuntimeError("input image is smaller than kernel")
+    _lib.check(rc, "ganet_deform_conv_forward")
+    return out
+
+
+class DeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx,
+                input,
+                offset,
+                weight,
+                stride=1,
+                padding=0,
+                dilation=1,
+                groups=1,
+                deformable_groups=1,
+                im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError(f'Expected 4D tensor as input, got {input.dim()}'
+                             'D tensor instead.')
+        ctx.stride = _pair(stride)
+        ctx.padding = _pair(padding)
+        ctx.dilation = _pair(dilation)
+        ctx.groups = groups
+        ctx.deformable_groups = deformable_groups
+        ctx.im2col_step = im2col_step
+        ctx.save_for_backward(input, offset, weight)
+
+        # raises ValueError for empty outputs exactly like the reference
+        DeformConvFunction._output_size(input, weight, ctx.padding,
+                                        ctx.dilation, ctx.stride)
+        if not input.is_cuda:
+            raise NotImplementedError
+        # the fused kernel has no im2col chunking; the divisibility contract
+        # of the reference API is kept (deform_conv.py:49-51)
+        cur_im2col_step = min(ctx.im2col_step, input.shape[0])
+        assert (input.shape[0] %
+                cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        return deform_conv_forward(input, offset, weight, ctx.stride,
+                                   ctx.padding, ctx.dilation, ctx.groups,
+                                   ctx.deformable_groups)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise NotImplementedError(
+            'ganet_amd: deform_conv backward is not built (inference hot path only)')
+
+    @staticmethod
+    def _output_size(input, weight, padding, dilation, stride):
+        channels = weight.size(0)
+        output_size = (input.size(0), channels)
+        for d in range(input.dim() - 2):
+            in_size = input.size(d + 2)
+            pad = padding[d]
+            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+            stride_ = stride[d]
+            output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1, )
+        if not all(map(lambda s: s > 0, output_size)):
+            raise ValueError('convolution input is too small (output would be '
+                             f'{"x".join(map(str, output_size))})')
+        return output_size
+
+
+class ModulatedDeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx,
+                input,
+                offset,
+                mask,
+                weight,
+                bias=None,
+                stride=1,
+                padding=0,
+                dilation=1,
+                groups=1,
+                deformable_groups=1):
+        ctx.stride = stride
+        ctx.padding = padding
+        ctx.dilation = dilation
+        ctx.groups = groups
+        ctx.deformable_groups = deformable_groups
+        ctx.with_bias = bias is not None
+        if not input.is_cuda:
+            raise NotImplementedError
+        return deform_conv_forward(input, offset, weight, _pair(stride),
+                                   _pair(padding), _pair(dilation), groups,
+                                   deformable_groups, mask=mask, bias=bias)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise NotImplementedError(
+            'ganet_amd: modulated_deform_conv backward is not built '
+            '(inference hot path only)')
+
+    @staticmethod
+    def _infer_shape(ctx, input, weight):
+        n = input.size(0)
+        channels_out = weight.size(0)
+        height, width = input.shape[2:4]
+        kernel_h, kernel_w = weight.shape[2:4]
+        height_out = (height + 2 * ctx.padding -
+                      (ctx.dilation * (kernel_h - 1) + 1)) // ctx.stride + 1
+        width_out = (width + 2 * ctx.padding -
+                     (ctx.dilation * (kernel_w - 1) + 1)) // ctx.stride + 1
+        return n, channels_out, height_out, width_out
+
+
+deform_conv = DeformConvFunction.apply
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class _DeformConvBase(nn.Module):
+    """Shared body of DeformConv / DeformConv1D (deform_conv.py:191-317)."""
+
+    def _init(self, in_channels, out_channels, kernel_size, stride, padding,
+              dilation, groups, deformable_groups, bias):
+        assert not bias
+        assert in_channels % groups == 0, \
+            f'in_channels {in_channels} is not divisible by groups {groups}'
+        assert out_channels % groups == 0, \
+            f'out_channels {out_channels} is not divisible ' \
+            f'by groups {groups}'
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        # enable compatibility with nn.Conv2d
+        self.transposed = False
+        self.output_padding = _single(0)
+        self.weight = nn.Parameter(
+            torch.Tensor(out_channels, in_channels // self.groups,
+                         *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        # input image smaller than the kernel: pad, run, crop
+        # (deform_conv.py:237-253 / :301-317)
+        input_pad = (
+            x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1])
+        if input_pad:
+            pad_h = max(self.kernel_size[0] - x.size(2), 0)
+            pad_w = max(self.kernel_size[1] - x.size(3), 0)
+            x = F.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+            offset = F.pad(offset, (0, pad_w, 0, pad_h), 'constant',
+                           0).contiguous()
+        out = deform_conv(x, offset, self.weight, self.stride, self.padding,
+                          self.dilation, self.groups, self.deformable_groups)
+        if input_pad:
+            out = out[:, :, :out.size(2) - pad_h, :out.size(3) -
+                      pad_w].contiguous()
+        return out
+
+
+class DeformConv(_DeformConvBase):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, deformable_groups=1,
+                 bias=False):
+        super(DeformConv, self).__init__()
+        self._init(in_channels, out_channels, _pair(kernel_size), _pair(stride),
+                   _pair(padding), _pair(dilation), groups, deformable_groups,
+                   bias)
+
+
+class DeformConv1D(_DeformConvBase):
+    """1 x K deformable convolution, the LFA's aggregation operator
+    (deform_conv.py:255-317; used at lanepoints_conv.py:104-106)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, deformable_groups=1,
+                 bias=False):
+        super(DeformConv1D, self).__init__()
+        self._init(in_channels, out_channels, (1, kernel_size), (1, stride),
+                   (0, padding), (1, dilation), groups, deformable_groups, bias)
+
+
+class DeformConvPack(DeformConv):
+    """Deformable conv that predicts its own offsets (deform_conv.py:320-387)."""
+
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super(DeformConvPack, self).__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(
+            self.in_channels,
+            self.deformable_groups * 2 * self.kernel_size[0] *
+            self.kernel_size[1],
+            kernel_size=self.kernel_size,
+            stride=_pair(self.stride),
+            padding=_pair(self.padding),
+            dilation=_pair(self.dilation),
+            bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding,
+                           self.dilation, self.groups, self.deformable_groups)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict,
+                              missing_keys, unexpected_keys, error_msgs):
+        _migrate_offset_keys(state_dict, prefix, local_metadata)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata,
+                                      strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+
+def _migrate_offset_keys(state_dict, prefix, local_metadata):
+    """Version < 2 checkpoints name the offset conv `<name>_offset`
+    (deform_conv.py:362-377, :486-502)."""
+    version = local_metadata.get('version', None)
+    if version is None or version < 2:
+        for leaf in ('weight', 'bias'):
+            new = prefix + 'conv_offset.' + leaf
+            old = prefix[:-1] + '_offset.' + leaf
+            if new not in state_dict and old in state_dict:
+                state_dict[new] = state_dict.pop(old)
+
+
+class ModulatedDeformConv(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, deformable_groups=1,
+                 bias=True):
+        super(ModulatedDeformConv, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.with_bias = bias
+        # enable compatibility with nn.Conv2d
+        self.transposed = False
+        self.output_padding = _single(0)
+
+        self.weight = nn.Parameter(
+            torch.Tensor(out_channels, in_channels // groups,
+                         *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
+                                     self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(
+            self.in_channels,
+            self.deformable_groups * 3 * self.kernel_size[0] *
+            self.kernel_size[1],
+            kernel_size=self.kernel_size,
+            stride=_pair(self.stride),
+            padding=_pair(self.padding),
+            dilation=_pair(self.dilation),
+            bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
+                                     self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict,
+                              missing_keys, unexpected_keys, error_msgs):
+        _migrate_offset_keys(state_dict, prefix, local_metadata)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata,
+                                      strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+
+def _register_with_mmcv():
+    """Register 'DCN' / 'DCNv2' with mmcv's CONV_LAYERS when mmcv is present
+    (deform_conv.py:320, :440); a no-op otherwise."""
+    try:
+        from mmcv.cnn import CONV_LAYERS
+    except Exception:
+        return False
+    CONV_LAYERS.register_module('DCN', module=DeformConvPack, force=True)
+    CONV_LAYERS.register_module('DCNv2', module=ModulatedDeformConvPack, force=True)
+    return True
+
+
+_register_with_mmcv()

@@ -1,0 +1,54 @@
+"""The Lane-aware Feature Aggregator's tail as one fused operator.
+
+Mirror of LanePointsConv.forward_single lines 170-172
+(mmdet/models/dense_heads/lanepoints_conv.py:141-174):
+
+    dcn_offset  = pts_out_init - dcn_base_offset
+    feature_out = relu(DeformConv1D(cls_feat, dcn_offset))
+
+The reference runs an elementwise subtract kernel, the deform-conv op and a
+ReLU kernel; here the subtraction happens while the sampling coordinates are
+formed and the ReLU in the contraction's epilogue.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .dcn import DeformConv1D, deform_conv_forward
+
+
+def dcn_base_offset(num_points, dtype=torch.float32, device=None):
+    """[0,-p, 0,-p+1, ..., 0,+p] shaped [1, 2K, 1, 1] (lanepoints_conv.py:63-74)."""
+    pad = int((num_points - 1) / 2)
+    base = np.arange(-pad, pad + 1).astype(np.float64)
+    off = np.stack([np.repeat(0, num_points), np.tile(base, 1)], axis=1).reshape(-1)
+    return torch.tensor(off).reshape(1, -1, 1, 1).to(dtype=dtype, device=device)
+
+
+class LaneAwareAggregator(nn.Module):
+    """`reppoints_cls_conv` + the offset subtraction + ReLU of LanePointsConv.
+
+    Holds the same parameter as the reference's DeformConv1D (`conv.weight`,
+    [Cout, Cin, 1, K], no bias), so a reference state dict loads unchanged
+    under the key `reppoints_cls_conv.weight` -> `conv.weight`.
+    """
+
+    def __init__(self, feat_channels=256, point_feat_channels=64, num_points=7):
+        super().__init__()
+        assert num_points % 2 == 1, 'The points number should be an odd number.'
+        self.num_points = num_points
+        self.dcn_pad = int((num_points - 1) / 2)
+        self.conv = DeformConv1D(feat_channels, point_feat_channels, num_points,
+                                 1, self.dcn_pad)
+
+    def forward(self, cls_feat, pts_out_init):
+        return deform_conv_forward(
+            cls_feat, pts_out_init, self.conv.weight, self.conv.stride,
+            self.conv.padding, self.conv.dilation, 1, 1, fuse_relu=True,
+            offset_is_points=True)
+
+    def forward_unfused(self, cls_feat, pts_out_init):
+        """The reference's three-step form (for parity tests)."""
+        base = dcn_base_offset(self.num_points, pts_out_init.dtype,
+                               pts_out_init.device)
+        return torch.relu(self.conv(cls_feat, (pts_out_init - base).contiguous()))

@@ -1,0 +1,196 @@
+/*
+ * ganet_hip.h - C-ABI of the MI355X (gfx950) implementation of GANet's hot path:
+ *   (1) the Lane-aware Feature Aggregator's deformable gather-and-aggregate
+ *       (DeformConv / DeformConv1D / ModulatedDeformConv forward), and
+ *   (2) the global keypoint-association decode (heat-map NMS, threshold,
+ *       ordered compaction, start-point regression, lane grouping).
+ *
+ * Plain C: pointers, sizes and PODs only - no torch / HIP types.  Every device
+ * pointer is caller-owned; the library never allocates or frees device memory
+ * in these calls (scratch comes in through the `workspace` arguments), never
+ * synchronises with the host, and enqueues only on the stream it is given.
+ * All entry points are re-entrant and hold no mutable global state; call them
+ * from one host thread per GPU with that GPU current.
+ *
+ * Citations are file:line in the reference tree (Wolfwjs/GANet).
+ */
+#ifndef GANET_HIP_H_
+#define GANET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANET_HIP_ABI_VERSION 1
+
+/* hipStream_t, passed opaquely (NULL = the default stream). */
+typedef void *ganet_stream_t;
+
+typedef enum {
+  GANET_OK = 0,
+  GANET_ERR_NULL = -1,        /* a required pointer is NULL */
+  GANET_ERR_BAD_SHAPE = -2,   /* shapes the reference's shape_check rejects */
+  GANET_ERR_UNSUPPORTED = -3, /* valid for the reference, not built here yet */
+  GANET_ERR_WORKSPACE = -4,   /* workspace_bytes smaller than the query says */
+  GANET_ERR_HIP = -5,         /* a HIP call / kernel launch failed */
+  GANET_ERR_TOO_SMALL = -6    /* convolution output would be empty */
+} ganet_status;
+
+typedef enum { GANET_F32 = 0, GANET_BF16 = 1, GANET_F16 = 2 } ganet_dtype;
+typedef enum { GANET_NCHW = 0, GANET_NHWC = 1 } ganet_layout;
+
+const char *ganet_status_string(int status);
+int ganet_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * (1) Deformable convolution forward.
+ *
+ * Replaces the pybind entry point
+ *   int deform_conv_forward(Tensor input, Tensor weight, Tensor offset,
+ *       Tensor output, Tensor columns, Tensor ones, int kW, int kH, int dW,
+ *       int dH, int padW, int padH, int dilationW, int dilationH, int group,
+ *       int deformable_group, int im2col_step)
+ *   mmdet/ops/dcn/src/deform_conv_ext.cpp:51-67 -> deform_conv_forward_cuda,
+ *   mmdet/ops/dcn/src/cuda/deform_conv_cuda.cpp:152-260,
+ * and, with `mask` (and optionally `bias`) non-NULL,
+ *   modulated_deform_conv_forward, deform_conv_ext.cpp:98-113 ->
+ *   deform_conv_cuda.cpp:490-569.
+ * It is called from DeformConvFunction.forward (mmdet/ops/dcn/deform_conv.py:52-57).
+ *
+ * There is no im2col buffer and no im2col_step chunking: sampling and the
+ * contraction are one fused kernel.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t B, Cin, H, W, Cout;
+  int32_t kH, kW;           /* weight.size(2), weight.size(3) */
+  int32_t sH, sW;           /* stride   ("dH, dW" in the reference signature) */
+  int32_t pH, pW;           /* padding */
+  int32_t dH, dW;           /* dilation */
+  int32_t groups;           /* conv groups */
+  int32_t deformable_groups;
+  int32_t dtype;            /* ganet_dtype of x, weight, (bias,) out.  offset and
+                               mask are always float32. */
+  int32_t x_layout;         /* ganet_layout of x */
+  int32_t out_layout;       /* ganet_layout of out */
+  int32_t mfma_bf16;        /* dtype == GANET_F32 only: 1 = round the sampled
+                               columns and the weights to bf16 and contract on
+                               the bf16 MFMA (fp32 accumulate); 0 = exact-fp32
+                               MFMA */
+  int32_t fuse_relu;        /* 1 = out = max(out, 0)
+                               (mmdet/models/dense_heads/lanepoints_conv.py:172) */
+  int32_t offset_is_points; /* 1 = `offset` holds the LFA's pts_out_init and the
+                               kernel subtracts the kernel-grid base itself
+                               (lanepoints_conv.py:63-74,170); needs kH == 1,
+                               dW == 1, pW == (kW-1)/2 */
+  int32_t reserved[3];
+} ganet_dcn_params;
+
+/* Output spatial size rule of the reference
+ * (mmdet/ops/dcn/deform_conv.py:98-111, deform_conv_cuda.cpp:108-111). */
+int ganet_dcn_out_size(int in, int pad, int dilation, int k, int stride);
+
+/* Bytes of device scratch `ganet_deform_conv_forward` needs for `p`
+ * (channel-last copy of x when x_layout is NCHW, repacked weights).
+ * Returns 0 for invalid parameters. */
+size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p);
+
+/* x      [B,Cin,H,W]  (or NHWC bytes when x_layout == GANET_NHWC), p->dtype
+ * offset [B, 2*dg*kH*kW, Hout, Wout] float32, channel 2t = dy, 2t+1 = dx of tap t
+ *        (deform_conv_cuda_kernel.cu:222-225)
+ * mask   NULL, or [B, dg*kH*kW, Hout, Wout] float32 (DCNv2)
+ * weight [Cout, Cin/groups, kH, kW], p->dtype
+ * bias   NULL, or [Cout], p->dtype (DCNv2 only)
+ * out    [B,Cout,Hout,Wout] (or NHWC), p->dtype; fully overwritten.
+ * Returns GANET_OK after enqueueing on `stream`; no host synchronisation. */
+int ganet_deform_conv_forward(const void *x, const float *offset,
+                              const float *mask, const void *weight,
+                              const void *bias, void *out,
+                              const ganet_dcn_params *p, void *workspace,
+                              size_t workspace_bytes, ganet_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * (2) Keypoint decode + lane grouping for a batch of images.
+ *
+ * Replaces, per image,
+ *   GANetHeadFast.ktdet_decode_fast(heat, offset, error, thr, root_thr)
+ *     mmdet/models/dense_heads/ganet_head.py:203-238
+ *   group_points_fast(kpt_seeds, cpt_seeds, thr, by_center_thr)
+ *     tools/ganet/post_process.py:141-194   (PostProcessor.__call__ :244-262)
+ * The reference handles one image per call; this entry point takes the whole
+ * batch in one launch sequence.
+ * ---------------------------------------------------------------------- */
+#define GANET_DECODE_MAX_CENTERS 2048 /* hard limit of max_centers / max_groups
+                                         in by-centre mode (kept in LDS) */
+#define GANET_DECODE_COUNT_STRIDE 8
+
+typedef struct {
+  int32_t B, H, W;
+  float kpt_thr;        /* `thr`: heat_nms > thr, compared in float32 */
+  float root_thr;       /* offset_y < root_thr, compared in float32 */
+  double cluster_thr;   /* PostProcessor.cluster_thr: used when by_center_thr < 0
+                           (update_coords_fast, post_process.py:142-153) */
+  double by_center_thr; /* PostProcessor.cluster_by_center_thr; < 0 means None */
+  int32_t max_kpts;     /* capacity of the per-image keypoint arrays */
+  int32_t max_centers;  /* capacity of the per-image centre arrays (<= 2048) */
+  int32_t max_groups;   /* capacity of the per-image group arrays */
+  int32_t flags;        /* bit0: skip grouping (decode only) */
+  int32_t reserved[4];
+} ganet_decode_params;
+
+/* Per-image outputs, device pointers, caller-owned, image b at index b*stride:
+ *   counts       [B][8] int32: [0] keypoints found, [1] centres found,
+ *                [2] groups, [3] overflow bits (1: keypoints > max_kpts,
+ *                2: centres > max_centers, 4: groups > max_groups; arrays then
+ *                hold a truncated, NOT reference-exact result), [4..7] reserved
+ *   centers_xy   [B][max_centers][2] int32 (x,y), x-major order
+ *                (= root_center_arr, ganet_head.py:217-219)
+ *   center_gid   [B][max_centers] int32 group of each centre (by-centre mode)
+ *   kpt_xy       [B][max_kpts][2] int32 (x,y), row-major order (ganet_head.py:231)
+ *   kpt_align    [B][max_kpts][2] float32 coord + error  (ganet_head.py:230,233)
+ *   kpt_root     [B][max_kpts][2] float32 coord + offset (ganet_head.py:229,232)
+ *   kpt_gid      [B][max_kpts] int32 group index, -1 = in no group
+ *   group_center [B][max_groups][2] int32 truncated mean centre
+ *                (choose_mean_point, post_process.py:38-41); by-centre mode only
+ *   group_count  [B][max_groups] int32 keypoints per group
+ */
+typedef struct {
+  int32_t *counts;
+  int32_t *centers_xy;
+  int32_t *center_gid;
+  int32_t *kpt_xy;
+  float *kpt_align;
+  float *kpt_root;
+  int32_t *kpt_gid;
+  int32_t *group_center;
+  int32_t *group_count;
+} ganet_decode_out;
+
+size_t ganet_decode_workspace_bytes(const ganet_decode_params *p);
+
+/* heat [B,1,H,W], offset [B,2,H,W] (ch0 = dx, ch1 = dy to the start point),
+ * error [B,2,H,W], all float32 NCHW, contiguous.
+ * Returns GANET_OK after enqueueing on `stream`; capacity overflow is reported
+ * per image in `counts` (device memory), not in the return value. */
+int ganet_decode_batch(const float *heat, const float *offset,
+                       const float *error, const ganet_decode_params *p,
+                       const ganet_decode_out *out, void *workspace,
+                       size_t workspace_bytes, ganet_stream_t stream);
+
+/* Grouping only, on lists that already sit in `out` on the device (written by
+ * an earlier ganet_decode_batch with flags bit0, or uploaded by the caller):
+ * reads counts[0..1], centers_xy and kpt_root; writes center_gid, kpt_gid,
+ * group_center, group_count and counts[2..3].  This is the device side of
+ *   PostProcessor.__call__(output, downscale)  tools/ganet/post_process.py:244-262
+ * when decode and grouping are requested separately, as the reference's
+ * callers do (tools/ganet/tusimple/test_dataset.py:193-196).
+ * Only B, max_*, cluster_thr and by_center_thr of `p` are used. */
+int ganet_group_batch(const ganet_decode_params *p, const ganet_decode_out *out,
+                      ganet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANET_HIP_H_ */

@@ -1,0 +1,121 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol that
+include/ganet_hip.h declares; host-side validation paths need no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from ganet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "ganet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ganet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_exports_match_header():
+    names = declared_functions()
+    assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "missing export %s" % n
+
+
+def test_status_strings_and_version():
+    L = _lib.lib()
+    assert L.ganet_abi_version() == 1
+    assert _lib.status_string(0) == "ok"
+    for code in range(-6, 0):
+        assert _lib.status_string(code) != "unknown status"
+    assert _lib.status_string(-99) == "unknown status"
+
+
+def test_out_size_rule():
+    L = _lib.lib()
+    # (in + 2*pad - (dil*(k-1)+1)) // stride + 1   (deform_conv.py:98-111)
+    assert L.ganet_dcn_out_size(100, 3, 1, 7, 1) == 100
+    assert L.ganet_dcn_out_size(40, 0, 1, 1, 1) == 40
+    assert L.ganet_dcn_out_size(7, 1, 2, 3, 2) == 3
+    assert L.ganet_dcn_out_size(2, 0, 1, 7, 1) == 0
+
+
+def _dcn_params(**kw):
+    p = _lib.DcnParams()
+    base = dict(B=2, Cin=64, H=8, W=16, Cout=64, kH=1, kW=7, sH=1, sW=1, pH=0,
+                pW=3, dH=1, dW=1, groups=1, deformable_groups=1, dtype=0,
+                x_layout=0, out_layout=0)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(p, k, v)
+    return p
+
+
+def test_dcn_workspace_and_validation_without_gpu():
+    L = _lib.lib()
+    p = _dcn_params()
+    ws = L.ganet_deform_conv_workspace_bytes(ctypes.byref(p))
+    # NCHW input: channel-last copy of x + packed weights
+    assert ws >= 2 * 8 * 16 * 64 * 4 + 7 * 64 * 64 * 4
+    p2 = _dcn_params(x_layout=1, out_layout=1)
+    assert L.ganet_deform_conv_workspace_bytes(ctypes.byref(p2)) >= 7 * 64 * 64 * 4
+    assert L.ganet_deform_conv_workspace_bytes(ctypes.byref(p2)) < ws
+    # invalid parameters are rejected on the host, before any HIP call
+    bad = _dcn_params(kW=0)
+    assert L.ganet_deform_conv_workspace_bytes(ctypes.byref(bad)) == 0
+    fake = ctypes.c_void_p(256)
+    for kw, code in [(dict(kW=0), _lib.GANET_ERR_BAD_SHAPE),
+                     (dict(sW=0), _lib.GANET_ERR_BAD_SHAPE),
+                     (dict(Cin=63, deformable_groups=2), _lib.GANET_ERR_BAD_SHAPE),
+                     (dict(W=2, pW=0), _lib.GANET_ERR_TOO_SMALL),
+                     (dict(groups=2), _lib.GANET_ERR_UNSUPPORTED),
+                     (dict(dtype=7), _lib.GANET_ERR_BAD_SHAPE)]:
+        q = _dcn_params(**kw)
+        rc = L.ganet_deform_conv_forward(fake, fake, None, fake, None, fake,
+                                         ctypes.byref(q), fake, 1 << 30, None)
+        assert rc == code, (kw, rc)
+    rc = L.ganet_deform_conv_forward(None, fake, None, fake, None, fake,
+                                     ctypes.byref(p), fake, 1 << 30, None)
+    assert rc == _lib.GANET_ERR_NULL
+    rc = L.ganet_deform_conv_forward(fake, fake, None, fake, None, fake,
+                                     ctypes.byref(p), fake, 16, None)
+    assert rc == _lib.GANET_ERR_WORKSPACE
+
+
+def test_decode_validation_without_gpu():
+    L = _lib.lib()
+    p = _lib.DecodeParams()
+    p.B, p.H, p.W = 4, 40, 100
+    p.max_kpts, p.max_centers, p.max_groups = 512, 64, 64
+    assert L.ganet_decode_workspace_bytes(ctypes.byref(p)) >= 4 * 63 * 8
+    out = _lib.DecodeOut()
+    fake = ctypes.c_void_p(256)
+    rc = L.ganet_decode_batch(fake, fake, fake, ctypes.byref(p), ctypes.byref(out),
+                              fake, 1 << 20, None)
+    assert rc == _lib.GANET_ERR_NULL          # output pointers are NULL
+    for n, _ in _lib.DecodeOut._fields_:
+        setattr(out, n, 256)
+    p.max_centers = 4096
+    rc = L.ganet_decode_batch(fake, fake, fake, ctypes.byref(p), ctypes.byref(out),
+                              fake, 1 << 20, None)
+    assert rc == _lib.GANET_ERR_UNSUPPORTED
+    p.max_centers = 64
+    rc = L.ganet_decode_batch(fake, fake, fake, ctypes.byref(p), ctypes.byref(out),
+                              fake, 8, None)
+    assert rc == _lib.GANET_ERR_WORKSPACE
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from ganet_amd import dcn, decode
+    x = torch.zeros(1, 64, 8, 16)
+    off = torch.zeros(1, 14, 8, 16)
+    m = dcn.DeformConv1D(64, 64, 7, 1, 3)
+    with pytest.raises(NotImplementedError):
+        m(x, off)
+    with pytest.raises(NotImplementedError):
+        decode.decode_batch(torch.zeros(1, 1, 8, 16), torch.zeros(1, 2, 8, 16),
+                            torch.zeros(1, 2, 8, 16))

@@ -1,0 +1,210 @@
+"""GPU parity of the fused deformable-convolution kernel (through the C-ABI and
+the module API) against the CPU oracle.  Tolerances, as the north star states:
+fp32 path <= 1e-4, bf16 / f16 paths <= 1e-2, relative to the output's scale."""
+import numpy as np
+import pytest
+import torch
+
+from ganet_amd import dcn, lfa, synth
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 1e-4
+TOL_16 = 1e-2
+
+
+def rel_err(got, ref):
+    ref = np.asarray(ref, np.float64)
+    got = np.asarray(got, np.float64)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def run_gpu(x, off, w, stride, pad, dil, dg=1, dtype=torch.float32, channels_last=False,
+            mask=None, bias=None, **kw):
+    xt = torch.from_numpy(x).cuda().to(dtype)
+    if channels_last:
+        xt = xt.contiguous(memory_format=torch.channels_last)
+    out = dcn.deform_conv_forward(
+        xt, torch.from_numpy(off).cuda(), torch.from_numpy(w).cuda().to(dtype),
+        stride, pad, dil, 1, dg,
+        mask=None if mask is None else torch.from_numpy(mask).cuda(),
+        bias=None if bias is None else torch.from_numpy(bias).cuda().to(dtype), **kw)
+    if channels_last:
+        assert out.is_contiguous(memory_format=torch.channels_last)
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy()
+
+
+def make(B, Cin, H, W, Cout, kH, kW, stride, pad, dil, dg, seed=0, scale=2.5):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, kH, kW)) / np.sqrt(Cin * kH * kW)).astype(np.float32)
+    Ho = O.dcn_out_size(H, pad[0], dil[0], kH, stride[0])
+    Wo = O.dcn_out_size(W, pad[1], dil[1], kW, stride[1])
+    off = (rng.standard_normal((B, dg * 2 * kH * kW, Ho, Wo)) * scale).astype(np.float32)
+    return x, off, w
+
+
+GENERIC = [
+    # B, Cin, H, W, Cout, kH, kW, stride, pad, dil, dg
+    (2, 64, 12, 20, 64, 1, 7, (1, 1), (0, 3), (1, 1), 1),
+    (1, 128, 9, 13, 32, 3, 3, (1, 1), (1, 1), (1, 1), 2),
+    (2, 64, 11, 14, 96, 3, 3, (2, 2), (1, 1), (1, 1), 1),    # Cout > 64: two N tiles
+    (1, 48, 10, 12, 20, 3, 3, (1, 1), (2, 2), (2, 2), 1),    # padded Cin / Cout
+    (3, 32, 7, 9, 8, 1, 9, (1, 1), (0, 4), (1, 1), 1),
+    (1, 256, 6, 10, 64, 1, 1, (1, 1), (0, 0), (1, 1), 4),    # 1x1, 4 deformable groups
+]
+
+
+@pytest.mark.parametrize("case", GENERIC)
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_fp32_generic_shapes(case, channels_last):
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w = make(*case)
+    ref = O.deform_conv_forward(x, off, w, st, pad, dil, 1, dg)
+    got = run_gpu(x, off, w, st, pad, dil, dg, channels_last=channels_last)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) <= TOL_F32
+
+
+@pytest.mark.parametrize("case", GENERIC[:4])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_16bit_generic_shapes(case, dtype):
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w = make(*case)
+    # the oracle sees the same rounded inputs the kernel reads
+    xr = torch.from_numpy(x).to(dtype).float().numpy()
+    wr = torch.from_numpy(w).to(dtype).float().numpy()
+    ref = O.deform_conv_forward(xr, off, wr, st, pad, dil, 1, dg)
+    for cl in (False, True):
+        got = run_gpu(x, off, w, st, pad, dil, dg, dtype=dtype, channels_last=cl)
+        assert rel_err(got, ref) <= TOL_16
+
+
+def test_fp32_storage_bf16_mfma():
+    case = GENERIC[0]
+    x, off, w = make(*case)
+    ref = O.deform_conv_forward(x, off, w, case[7], case[8], case[9], 1, case[10])
+    got = run_gpu(x, off, w, case[7], case[8], case[9], case[10], mfma_bf16=True)
+    assert rel_err(got, ref) <= TOL_16
+    exact = run_gpu(x, off, w, case[7], case[8], case[9], case[10], mfma_bf16=False)
+    assert rel_err(exact, ref) <= TOL_F32
+
+
+@pytest.mark.parametrize("shape,B,Cin", [("s8_tusimple", 2, 256), ("s8_tusimple", 3, 64),
+                                         ("s4_culane", 1, 256)])
+def test_lfa_shapes_fp32_and_bf16(shape, B, Cin):
+    """The LFA's own shapes (C1/C2/C4) on the synthetic lane offsets."""
+    cfg = synth.SHAPES[shape]
+    K = cfg["K"]
+    x, off, w, pts = synth.lfa_inputs(B, Cin, cfg["H"], cfg["W"], K, Cout=64, seed=1)
+    ref = O.deform_conv_forward(x, off, w, (1, 1), (0, (K - 1) // 2), (1, 1), nthreads=8)
+    got = run_gpu(x, off, w, (1, 1), (0, (K - 1) // 2), (1, 1))
+    assert rel_err(got, ref) <= TOL_F32
+    got_cl = run_gpu(x, off, w, (1, 1), (0, (K - 1) // 2), (1, 1), channels_last=True)
+    assert rel_err(got_cl, ref) <= TOL_F32
+    xr = torch.from_numpy(x).bfloat16().float().numpy()
+    wr = torch.from_numpy(w).bfloat16().float().numpy()
+    ref16 = O.deform_conv_forward(xr, off, wr, (1, 1), (0, (K - 1) // 2), (1, 1), nthreads=8)
+    got16 = run_gpu(x, off, w, (1, 1), (0, (K - 1) // 2), (1, 1), dtype=torch.bfloat16,
+                    channels_last=True)
+    assert rel_err(got16, ref16) <= TOL_16
+
+
+def test_modulated_with_bias_and_relu():
+    rng = np.random.default_rng(7)
+    B, Cin, H, W, Cout, k, dg = 2, 64, 9, 11, 40, 3, 2
+    x, off, w = make(B, Cin, H, W, Cout, k, k, (1, 1), (1, 1), (1, 1), dg, seed=7)
+    mask = rng.uniform(0, 1, (B, dg * k * k, H, W)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    ref = O.deform_conv_forward(x, off, w, (1, 1), (1, 1), (1, 1), 1, dg, mask=mask, bias=bias)
+    got = run_gpu(x, off, w, (1, 1), (1, 1), (1, 1), dg, mask=mask, bias=bias)
+    assert rel_err(got, ref) <= TOL_F32
+    got_relu = run_gpu(x, off, w, (1, 1), (1, 1), (1, 1), dg, mask=mask, bias=bias,
+                       fuse_relu=True, channels_last=True)
+    assert rel_err(got_relu, np.maximum(ref, 0)) <= TOL_F32
+
+
+def test_known_answers_on_gpu():
+    # zero offsets == plain convolution
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 64, 10, 16)).astype(np.float32)
+    w = (rng.standard_normal((64, 64, 1, 7)) / 20).astype(np.float32)
+    off = np.zeros((2, 14, 10, 16), np.float32)
+    got = run_gpu(x, off, w, (1, 1), (0, 3), (1, 1))
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(),
+                                     torch.from_numpy(w).double(), padding=(0, 3)).numpy()
+    assert rel_err(got, ref) <= TOL_F32
+    # samples exactly at -1 / H / W contribute nothing (strict comparisons)
+    x = np.ones((1, 32, 6, 8), np.float32)
+    w = np.zeros((1, 32, 1, 1), np.float32)
+    w[0, 0] = 1.0
+    off = np.zeros((1, 2, 6, 8), np.float32)
+    off[0, 0, 0, :] = -1.0
+    off[0, 0, 5, :] = 1.0
+    off[0, 1, 2, 0] = -1.0
+    off[0, 1, 3, 7] = 1.0
+    off[0, 0, 1, 3] = -1.5
+    got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1))[0, 0]
+    assert np.all(got[0] == 0) and np.all(got[5] == 0)
+    assert got[2, 0] == 0 and got[3, 7] == 0 and got[1, 3] == 0.5 and got[4, 4] == 1.0
+    # NaN / inf outside the sampled support must not leak (v = 0, not w = 0)
+    x = np.ones((1, 32, 6, 8), np.float32)
+    x[0, :, 0, 0] = np.inf
+    off = np.zeros((1, 2, 6, 8), np.float32)
+    got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1))[0, 0]
+    assert np.isinf(got[0, 0]) and np.isfinite(got[0, 1:]).all() and np.isfinite(got[1:]).all()
+
+
+def test_module_api_like_the_reference():
+    torch.manual_seed(0)
+    m = dcn.DeformConv1D(64, 64, 7, 1, 3).cuda()
+    assert tuple(m.weight.shape) == (64, 64, 1, 7)
+    assert list(m.state_dict().keys()) == ["weight"]
+    x = torch.randn(2, 64, 10, 25, device="cuda")
+    off = torch.randn(2, 14, 10, 25, device="cuda")
+    y = m(x, off)
+    ref = O.deform_conv_forward(x.cpu().numpy(), off.cpu().numpy(),
+                                m.weight.detach().cpu().numpy(), (1, 1), (0, 3), (1, 1))
+    assert rel_err(y.detach().cpu().numpy(), ref) <= TOL_F32
+    # input narrower than the kernel: padded, run, cropped (deform_conv.py:301-317)
+    xs = torch.randn(1, 64, 4, 5, device="cuda")
+    offs = torch.randn(1, 14, 4, 5, device="cuda")
+    ys = m(xs, offs)
+    assert tuple(ys.shape) == (1, 64, 4, 5)
+    xp = torch.nn.functional.pad(xs, (0, 2, 0, 0)).cpu().numpy()
+    op = torch.nn.functional.pad(offs, (0, 2, 0, 0)).cpu().numpy()
+    refs = O.deform_conv_forward(xp, op, m.weight.detach().cpu().numpy(), (1, 1), (0, 3),
+                                 (1, 1))[:, :, :, :5]
+    assert rel_err(ys.detach().cpu().numpy(), refs) <= TOL_F32
+    # error behaviour of the reference
+    with pytest.raises(ValueError):
+        dcn.deform_conv(x[0], off, m.weight)
+    with pytest.raises(AssertionError):
+        dcn.DeformConv(64, 64, 3, bias=True)
+    with pytest.raises(AssertionError):
+        dcn.deform_conv(torch.randn(3, 64, 10, 25, device="cuda"),
+                        torch.randn(3, 14, 10, 25, device="cuda"), m.weight, (1, 1), (0, 3),
+                        (1, 1), 1, 1, 2)
+    pack = dcn.DeformConvPack(64, 64, 3, padding=1).cuda()
+    yp = pack(x)
+    refp = torch.nn.functional.conv2d(x, pack.weight, padding=1)   # zero-init offsets
+    assert rel_err(yp.detach().cpu().numpy(), refp.detach().cpu().numpy()) <= TOL_F32
+    mpack = dcn.ModulatedDeformConvPack(64, 32, 3, padding=1).cuda()
+    ym = mpack(x)
+    refm = 0.5 * torch.nn.functional.conv2d(x, mpack.weight, padding=1)  # sigmoid(0) mask
+    assert rel_err(ym.detach().cpu().numpy(), refm.detach().cpu().numpy()) <= TOL_F32
+
+
+def test_fused_lfa_tail_matches_unfused():
+    agg = lfa.LaneAwareAggregator(256, 64, 7).cuda()
+    x, off, w, pts = synth.lfa_inputs(2, 256, 40, 100, 7, seed=4)
+    with torch.no_grad():
+        agg.conv.weight.copy_(torch.from_numpy(w))
+        xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(pts).cuda()
+        fused = agg(xt, pt)
+        unfused = agg.forward_unfused(xt, pt)
+    assert torch.equal(fused, unfused)   # same kernel arithmetic, bit for bit
+    ref = np.maximum(O.deform_conv_forward(x, off, w, (1, 1), (0, 3), (1, 1), nthreads=8), 0)
+    assert rel_err(fused.cpu().numpy(), ref) <= TOL_F32

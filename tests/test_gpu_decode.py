@@ -1,0 +1,153 @@
+"""GPU parity: the HIP decode + grouping (through the C-ABI) against the golden
+vectors of the real reference and against the CPU oracle.  Bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from ganet_amd import decode as D
+from ganet_amd import synth
+from ganet_amd.post_process import PostProcessor, lanes_from_image
+from oracle import cpu_oracle as O
+from tests.golden_util import (assert_bits_equal, golden_names, lanes_to_arrays,
+                               load_decode_case)
+
+pytestmark = pytest.mark.gpu
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def check_image_against(img, centers, align, root, gid, means, ng):
+    assert_bits_equal(img["centers"].astype(np.int64), centers, "centres")
+    assert_bits_equal(np.array(img["align"]), align, "align")
+    assert_bits_equal(np.array(img["root"]), root, "root")
+    assert img["n_groups"] == ng
+    assert_bits_equal(np.array(img["kpt_gid"]), gid, "kpt_gid")
+    assert_bits_equal(img["group_center"].astype(np.int64).reshape(-1, 2), means,
+                      "group means")
+    counts = np.bincount(gid[gid >= 0], minlength=ng)
+    assert np.array_equal(img["group_count"], counts)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_decode_batch_matches_reference_golden(name):
+    d = load_decode_case(name)
+    res = D.decode_batch(cuda(d["heat"]), cuda(d["offset"]), cuda(d["error"]),
+                         thr=float(d["thr"]), root_thr=float(d["root_thr"]),
+                         cluster_thr=float(d["T"]),
+                         cluster_by_center_thr=d["by_center_thr"])
+    img = res.image(0)
+    check_image_against(img, d["root_center_arr"], d["align"],
+                        d["root"].astype(np.float32), d["kpt_gid"], d["group_means"],
+                        int(d["n_groups"]))
+    assert np.array_equal(np.array(img["root"]).astype(np.float64), d["root"])
+    lanes, cc = lanes_from_image(img, int(d["ds"]))
+    ids, sizes, pts, ctr, ccs = lanes_to_arrays(lanes, cc)
+    assert_bits_equal(ids, d["lane_ids"], "lane ids")
+    assert_bits_equal(sizes, d["lane_sizes"], "lane sizes")
+    assert_bits_equal(pts, d["lane_points"], "lane points")
+    assert_bits_equal(ctr, d["lane_centers"], "lane centres")
+    assert_bits_equal(ccs, d["cluster_centers"], "cluster centres")
+
+
+@pytest.mark.parametrize("name", ["s8_tusimple_seed0", "random_1", "random_1_nocenter",
+                                  "edge_exact_distance_bridge", "edge_empty"])
+def test_reference_call_sequence(name):
+    """ktdet_decode_fast -> PostProcessor, as tools/ganet/*/test_dataset.py call
+    them; structures and dtypes as the reference returns them."""
+    d = load_decode_case(name)
+    cpt, kpt = D.ktdet_decode_fast(cuda(d["heat"]), cuda(d["offset"]), cuda(d["error"]),
+                                   thr=float(d["thr"]), root_thr=float(d["root_thr"]))
+    assert isinstance(cpt, np.ndarray) and cpt.dtype == np.int64
+    assert_bits_equal(cpt, d["root_center_arr"], "root_center_arr")
+    assert isinstance(kpt, list) and len(kpt) == len(d["align"])
+    for (a, r), ga, gr in zip(kpt, d["align"], d["root"]):
+        assert a.dtype == np.float32 and r.dtype == np.float64
+        assert a.tobytes() == ga.tobytes() and r.tobytes() == gr.tobytes()
+    pp = PostProcessor(cluster_thr=float(d["T"]),
+                       cluster_by_center_thr=d["by_center_thr"], group_fast=True)
+    lanes, cc = pp((cpt, kpt), int(d["ds"]))
+    ids, sizes, pts, ctr, ccs = lanes_to_arrays(lanes, cc)
+    assert_bits_equal(ids, d["lane_ids"], "lane ids")
+    assert_bits_equal(pts, d["lane_points"], "lane points")
+    assert_bits_equal(ctr, d["lane_centers"], "lane centres")
+    assert_bits_equal(ccs, d["cluster_centers"], "cluster centres")
+    # seeds that only exist on the host (plain lists) are grouped on the GPU too
+    lanes2, cc2 = pp((np.array(cpt), [(a, r) for a, r in kpt]), int(d["ds"]))
+    ids2, sizes2, pts2, ctr2, ccs2 = lanes_to_arrays(lanes2, cc2)
+    assert_bits_equal(ids2, d["lane_ids"], "lane ids (host seeds)")
+    assert_bits_equal(pts2, d["lane_points"], "lane points (host seeds)")
+    assert_bits_equal(ccs2, d["cluster_centers"], "cluster centres (host seeds)")
+
+
+@pytest.mark.parametrize("shape,B,by_center", [("s8_culane", 128, True),
+                                               ("s4_culane", 32, True),
+                                               ("dense_s8", 8, True),
+                                               ("s8_tusimple", 16, False)])
+def test_batch_against_oracle(shape, B, by_center):
+    """BASELINE.json shapes at batch size, every image bit-exact vs the oracle."""
+    cfg = synth.SHAPES[shape]
+    heat, off, err = synth.decode_inputs(B, cfg["H"], cfg["W"], lanes=cfg["lanes"], seed=11)
+    T = float(cfg["T"])
+    res = D.decode_batch(cuda(heat), cuda(off), cuda(err), thr=cfg["thr"],
+                         root_thr=cfg["root_thr"], cluster_thr=T,
+                         cluster_by_center_thr=T if by_center else None)
+    assert res.B == B
+    for b in range(B):
+        c, kxy, al, rt = O.decode(heat[b], off[b], err[b], cfg["thr"], cfg["root_thr"])
+        gid, means, cgid, ng = O.group_fast(c, rt, T, T if by_center else None)
+        img = res.image(b)
+        check_image_against(img, c, al, rt, gid, means, ng)
+        assert np.array_equal(img["kpt_xy"], kxy)
+        if by_center:
+            assert np.array_equal(img["center_gid"], cgid)
+
+
+def test_capacity_growth_and_noise_stress():
+    """Uniform-noise heat-maps with a low threshold: thousands of keypoints and
+    hundreds of centres per image; the default capacities overflow and regrow."""
+    rng = np.random.default_rng(5)
+    B, H, W = 6, 48, 96
+    heat = rng.uniform(0, 1, (B, 1, H, W)).astype(np.float32)
+    off = rng.normal(0, 2.5, (B, 2, H, W)).astype(np.float32)
+    err = rng.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
+    for by_center in (4.0, None):
+        res = D.decode_batch(cuda(heat), cuda(off), cuda(err), thr=0.3, root_thr=1,
+                             cluster_thr=3.0, cluster_by_center_thr=by_center,
+                             max_kpts=64, max_centers=16)
+        for b in range(B):
+            c, kxy, al, rt = O.decode(heat[b], off[b], err[b], 0.3, 1.0)
+            gid, means, cgid, ng = O.group_fast(c, rt, 3.0, by_center)
+            assert len(al) > 1000
+            check_image_against(res.image(b), c, al, rt, gid, means, ng)
+
+
+def test_size_independent_properties_dense_s4():
+    """Full-size dense frame (320x800, 16 lanes, thr 0.05): properties that hold
+    whatever the size - ordering, idempotence, consistency of counts."""
+    cfg = synth.SHAPES["dense_s4"]
+    heat, off, err = synth.decode_inputs(2, cfg["H"], cfg["W"], lanes=16, seed=3)
+    T = float(cfg["T"])
+    args = dict(thr=cfg["thr"], root_thr=1.0, cluster_thr=T, cluster_by_center_thr=T)
+    r1 = D.decode_batch(cuda(heat), cuda(off), cuda(err), **args)
+    r2 = D.decode_batch(cuda(heat), cuda(off), cuda(err), **args)
+    for b in range(2):
+        a, c = r1.image(b), r2.image(b)
+        for k in ("centers", "kpt_xy", "align", "root", "kpt_gid", "group_center"):
+            assert np.array_equal(a[k], c[k])                       # deterministic
+        kxy = a["kpt_xy"].astype(np.int64)
+        lin = kxy[:, 1] * cfg["W"] + kxy[:, 0]
+        assert np.all(np.diff(lin) > 0)                              # row-major, unique
+        cx = a["centers"].astype(np.int64)
+        assert np.all(np.diff(cx[:, 0] * cfg["H"] + cx[:, 1]) > 0)  # x-major, unique
+        assert a["group_count"].sum() == (a["kpt_gid"] >= 0).sum()
+        assert a["kpt_gid"].max() < a["n_groups"]
+        # every keypoint is a strict 1x3 local max above the threshold
+        h = heat[b, 0]
+        v = h[kxy[:, 1], kxy[:, 0]]
+        assert np.all(v > np.float32(cfg["thr"]))
+    # and the oracle agrees on one full-size image
+    c, kxy, al, rt = O.decode(heat[0], off[0], err[0], cfg["thr"], 1.0)
+    gid, means, cgid, ng = O.group_fast(c, rt, T, T)
+    check_image_against(r1.image(0), c, al, rt, gid, means, ng)
