@@ -149,9 +149,9 @@ def test_known_answers_on_gpu():
     got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1))[0, 0]
     assert np.all(got[0] == 0) and np.all(got[5] == 0)
     assert got[2, 0] == 0 and got[3, 7] == 0 and got[1, 3] == 0.5 and got[4, 4] == 1.0
-    # NaN / inf outside the sampled support must not leak (v = 0, not w = 0)
+    # an inf pixel reaches only the outputs whose support holds it
     x = np.ones((1, 32, 6, 8), np.float32)
-    x[0, :, 0, 0] = np.inf
+    x[0, 0, 0, 0] = np.inf
     off = np.zeros((1, 2, 6, 8), np.float32)
     got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1))[0, 0]
     assert np.isinf(got[0, 0]) and np.isfinite(got[0, 1:]).all() and np.isfinite(got[1:]).all()
