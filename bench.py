@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""bench.py - images/s of GANet's hot path (LFA + keypoint decode) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3] [--dtype bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input that is
+already resident in HBM: the fused LFA kernel (relu(DeformConv1D(x, pts - base)))
+followed by decode + lane grouping of the same batch and the async D2H copy of
+the compact lane lists.  Images are independent, so on N GPUs each rank owns
+its own batch of the same size (weak scaling) and NO collective is on the data
+path; torch.distributed is used only for the barrier / max-over-ranks timing
+the driver's contract asks for.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3}
+
+WORKLOADS = {
+    # name: shape key in ganet_amd.synth.SHAPES, per-GPU batch, Cin, default dtype, decode?
+    "c3": dict(shape="s8_culane", B=128, Cin=256, dtype="bf16", decode=True,
+               desc="C3 full head hot path: LFA (Cin256->64, K7) + NMS/decode/grouping, "
+                    "CULane 320x800 (40x100 @ s8), batch 128 per GPU"),
+    "c2": dict(shape="s8_tusimple", B=32, Cin=256, dtype="fp32", decode=False,
+               desc="C2 LFA alone: Cin256->64, K7, 40x100, batch 32, fp32"),
+    "c2_c64": dict(shape="s8_tusimple", B=32, Cin=64, dtype="fp32", decode=False,
+                   desc="C2 variant: LFA alone with C=64 in/out, K7, 40x100, batch 32, fp32"),
+    "c4": dict(shape="s4_culane", B=128, Cin=256, dtype="bf16", decode=True,
+               desc="C4 GANet-L head shapes: LFA (Cin256->64, K9) + decode, 80x200 @ s4, "
+                    "batch 128 per GPU (1024 over 8)"),
+    "c5": dict(shape="dense_s8", B=32, Cin=256, dtype="bf16", decode=True,
+               desc="C5 dense stress: 1280x3200 frames (160x400 @ s8), 16 lanes, thr 0.05, "
+                    "batch 32 per GPU (256 over 8)"),
+}
+TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}
+ESIZE = {"bf16": 2, "f16": 2, "fp32": 4}
+
+
+def lfa_algorithmic(B, Cin, Cout, H, W, K, dtype):
+    """Algorithmic HBM bytes and MFMA FLOPs of one LFA launch:
+    x + offsets(f32) + out once per image, weights once per launch."""
+    e = ESIZE[dtype]
+    hw = H * W
+    per_image = e * Cin * hw + 4 * 2 * K * hw + e * Cout * hw
+    nbytes = B * per_image + e * Cout * Cin * K
+    flops = B * 2.0 * Cout * Cin * K * hw
+    return nbytes, flops
+
+
+def decode_algorithmic(B, H, W):
+    """5 float32 planes read once per image."""
+    return B * 5 * 4 * H * W
+
+
+def build_inputs(wl, dtype, dev, seed):
+    from ganet_amd import synth
+    cfg = synth.SHAPES[wl["shape"]]
+    B, H, W, K, Cin = wl["B"], cfg["H"], cfg["W"], cfg["K"], wl["Cin"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.randn((B, Cin, H, W), generator=g, device=dev, dtype=torch.float32)
+    x = x.to(TORCH_DTYPE[dtype]).contiguous(memory_format=torch.channels_last)
+    pts, _ = synth.lfa_points(B, H, W, K, seed=seed)
+    w = synth.lfa_weight(Cin, K, 64, seed=seed)
+    d = dict(x=x, pts=torch.from_numpy(pts).to(dev), w=torch.from_numpy(w).to(dev),
+             cfg=cfg, pts_host=pts, w_host=w)
+    if wl["decode"]:
+        heat, off, err = synth.decode_inputs(B, H, W, lanes=cfg["lanes"], seed=seed)
+        d.update(heat=torch.from_numpy(heat).to(dev), off=torch.from_numpy(off).to(dev),
+                 err=torch.from_numpy(err).to(dev), heat_host=heat, off_host=off,
+                 err_host=err)
+    return d
+
+
+def cpu_baseline_and_parity(wl, dtype, d, hp, n_images, threads):
+    """Rank 0, N=1: the CPU oracle ("port" of the reference's algorithm) timed on
+    a bounded sample of the SAME inputs, and used as the checker of the GPU
+    result of that sample.  Never part of the measured GPU path."""
+    from oracle import cpu_oracle as O
+    cfg = d["cfg"]
+    K = cfg["K"]
+    n = min(n_images, wl["B"])
+    x_host = d["x"][:n].float().cpu().numpy()            # what the kernel read
+    w_host = d["w"].to(TORCH_DTYPE[dtype]).float().cpu().numpy()
+    base = np.zeros((2 * K, 1, 1), np.float32)
+    base[1::2, 0, 0] = np.arange(-(K - 1) // 2, (K - 1) // 2 + 1)
+    off_host = d["pts_host"][:n] - base[None]
+    t0 = time.perf_counter()
+    ref = O.deform_conv_forward(x_host, off_host, w_host, (1, 1), (0, (K - 1) // 2),
+                                (1, 1), acc64=False, nthreads=threads)
+    ref = np.maximum(ref, 0)
+    t_lfa = time.perf_counter() - t0
+    t_dec = 0.0
+    parity = {}
+    got = hp.feature[:n].float().cpu().numpy()
+    parity["lfa_rel_err"] = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+    parity["lfa_tolerance"] = 1e-4 if dtype == "fp32" else 1e-2
+    parity["lfa_ok"] = bool(parity["lfa_rel_err"] <= parity["lfa_tolerance"])
+    if wl["decode"]:
+        T = float(cfg["T"])
+        t0 = time.perf_counter()
+        O.decode_group_batch(d["heat_host"][:n], d["off_host"][:n], d["err_host"][:n],
+                             cfg["thr"], cfg["root_thr"], T, T, nthreads=threads)
+        t_dec = time.perf_counter() - t0
+        res = hp.result()
+        ok = True
+        for b in range(min(n, 8)):
+            c, kxy, al, rt = O.decode(d["heat_host"][b], d["off_host"][b],
+                                      d["err_host"][b], cfg["thr"], cfg["root_thr"])
+            gid, means, cgid, ng = O.group_fast(c, rt, T, T)
+            img = res.image(b)
+            ok &= bool(np.array_equal(img["centers"], c)
+                       and img["align"].tobytes() == al.tobytes()
+                       and img["root"].tobytes() == rt.tobytes()
+                       and np.array_equal(img["kpt_gid"], gid)
+                       and np.array_equal(img["group_center"], means))
+        parity["decode_bit_exact"] = ok
+    total = t_lfa + t_dec
+    return dict(value=n / total, unit="images/s", cores=threads, kind="port",
+                sample="%d of the %d images of the timed batch (same seeded inputs): "
+                       "oracle LFA fp32 %.2fs + decode/grouping %.3fs, OpenMP over images"
+                       % (n, wl["B"], t_lfa, t_dec),
+                lfa_images_per_s=n / t_lfa,
+                decode_images_per_s=(n / t_dec) if t_dec > 0 else None), parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "fp32"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
+    ap.add_argument("--cpu-images", type=int, default=32)
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=dev)
+
+    from ganet_amd import _lib
+    from ganet_amd.pipeline import HotPath
+    _lib.lib()
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    dtype = args.dtype or wl["dtype"]
+    d = build_inputs(wl, dtype, dev, args.seed + 1000 * rank)
+    cfg = d["cfg"]
+    B, H, W, K, Cin = wl["B"], cfg["H"], cfg["W"], cfg["K"], wl["Cin"]
+    T = float(cfg["T"])
+    hp = HotPath(B, H, W, Cin=Cin, Cout=64, K=K, dtype=TORCH_DTYPE[dtype], device=dev,
+                 thr=cfg["thr"], root_thr=cfg["root_thr"], cluster_thr=T, by_center_thr=T,
+                 max_kpts=min(H * W, 4096 if cfg["lanes"] > 4 else 1024),
+                 max_centers=256)
+    hp.set_weight(d["w"])
+
+    def one_step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        hp.lfa(d["x"], d["pts"])
+        if ev is not None:
+            ev[1].record()
+        if wl["decode"]:
+            hp.decode(d["heat"], d["off"], d["err"])
+            if ev is not None:
+                ev[2].record()
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if wl["decode"]:
+        over = int(np.bitwise_or.reduce(hp.result().v["counts"][:, 3]))
+        if over:
+            raise SystemExit("decode capacity overflow in the bench configuration")
+
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)]
+              for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(events[i])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    lfa_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if wl["decode"] else 0.0
+
+    if rank == 0:
+        nbytes, flops = lfa_algorithmic(B, Cin, 64, H, W, K, dtype)
+        t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
+        t_mfma = flops / (MFMA_PEAK_TFLOPS[dtype] * 1e12)
+        lfa_s = lfa_ms * 1e-3
+        hbm_achieved = nbytes / lfa_s / 1e9
+        mfma_achieved = flops / lfa_s / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("%s_%s" % (args.workload, dtype))
+            except Exception:
+                traffic = None
+        if t_mfma >= t_hbm:
+            roof = dict(bound="mfma", achieved=mfma_achieved,
+                        peak=MFMA_PEAK_TFLOPS[dtype], unit="TFLOP/s",
+                        frac=mfma_achieved / MFMA_PEAK_TFLOPS[dtype])
+        else:
+            roof = dict(bound="hbm", achieved=hbm_achieved, peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=hbm_achieved / HBM_PEAK_GBS)
+        roof.update(traffic=traffic, kernel="dcn_fused_kernel",
+                    kernel_ms=lfa_ms, algorithmic_bytes=nbytes, algorithmic_flops=flops,
+                    hbm_gbs=hbm_achieved, hbm_frac=hbm_achieved / HBM_PEAK_GBS,
+                    mfma_tflops=mfma_achieved,
+                    mfma_frac=mfma_achieved / MFMA_PEAK_TFLOPS[dtype],
+                    roofline_time_frac=max(t_hbm, t_mfma) / lfa_s)
+        out = {
+            "metric": "images/sec (LFA+decode, 320x800)" if wl["decode"]
+                      else "images/sec (LFA alone)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "name": args.workload,
+                       "batch_per_gpu": B, "global_batch": world * B,
+                       "feature_hw": [H, W], "cin": Cin, "cout": 64, "k": K,
+                       "layout": "NHWC (channels_last) resident in HBM",
+                       "parallelism": "image-sharded x%d, no collective" % world},
+            "roofline": roof,
+            "lfa_ms": lfa_ms,
+            "decode_ms": dec_ms,
+            "lfa_images_per_s_per_gpu": B / lfa_s,
+        }
+        if wl["decode"]:
+            dbytes = decode_algorithmic(B, H, W)
+            out["decode_images_per_s_per_gpu"] = B / (dec_ms * 1e-3)
+            out["decode_hbm_gbs"] = dbytes / (dec_ms * 1e-3) / 1e9
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            base, parity = cpu_baseline_and_parity(wl, dtype, d, hp, args.cpu_images,
+                                                   threads)
+            out["cpu_baseline"] = base
+            out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,7 @@ DECODE_COUNT_STRIDE = 8
 EXPORTS = (
     "ganet_status_string", "ganet_abi_version", "ganet_dcn_out_size",
     "ganet_deform_conv_workspace_bytes", "ganet_deform_conv_forward",
+    "ganet_deform_conv_packed_weight_bytes", "ganet_deform_conv_pack_weight",
     "ganet_decode_workspace_bytes", "ganet_decode_batch", "ganet_group_batch",
 )
 
@@ -32,8 +33,8 @@ class DcnParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "Cin", "H", "W", "Cout", "kH", "kW", "sH", "sW", "pH", "pW", "dH",
         "dW", "groups", "deformable_groups", "dtype", "x_layout", "out_layout",
-        "mfma_bf16", "fuse_relu", "offset_is_points")] + [
-        ("reserved", ctypes.c_int32 * 3)]
+        "mfma_bf16", "fuse_relu", "offset_is_points", "weight_is_packed")] + [
+        ("reserved", ctypes.c_int32 * 2)]
 
 
 class DecodeParams(ctypes.Structure):
@@ -82,6 +83,12 @@ def lib():
         L.ganet_deform_conv_forward.argtypes = [
             ctypes.c_void_p] * 6 + [ctypes.POINTER(DcnParams), ctypes.c_void_p,
                                     ctypes.c_size_t, ctypes.c_void_p]
+        L.ganet_deform_conv_packed_weight_bytes.restype = ctypes.c_size_t
+        L.ganet_deform_conv_packed_weight_bytes.argtypes = [ctypes.POINTER(DcnParams)]
+        L.ganet_deform_conv_pack_weight.restype = ctypes.c_int
+        L.ganet_deform_conv_pack_weight.argtypes = [
+            ctypes.c_void_p, ctypes.POINTER(DcnParams), ctypes.c_void_p,
+            ctypes.c_size_t, ctypes.c_void_p]
         L.ganet_decode_workspace_bytes.restype = ctypes.c_size_t
         L.ganet_decode_workspace_bytes.argtypes = [ctypes.POINTER(DecodeParams)]
         L.ganet_decode_batch.restype = ctypes.c_int

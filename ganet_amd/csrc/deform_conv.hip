@@ -521,7 +521,40 @@ extern "C" int ganet_dcn_out_size(int in, int pad, int dilation, int k,
 extern "C" size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p) {
   Plan pl;
   if (make_plan(p, &pl) != GANET_OK) return 0;
-  return pl.xh_bytes + pl.wp_bytes;
+  return pl.xh_bytes + (p->weight_is_packed ? 0 : pl.wp_bytes);
+}
+
+extern "C" size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p) {
+  Plan pl;
+  if (make_plan(p, &pl) != GANET_OK) return 0;
+  return pl.wp_bytes;
+}
+
+namespace {
+int pack_weight_dispatch(const ganet_dcn_params *p, const Plan &pl,
+                         const void *weight, void *wp, hipStream_t s) {
+  if (p->dtype == GANET_F32 && pl.ta == GANET_F32)
+    launch_pack_weight<float, float>(p, pl, weight, wp, s);
+  else if (p->dtype == GANET_F32 && pl.ta == GANET_BF16)
+    launch_pack_weight<float, bf16_t>(p, pl, weight, wp, s);
+  else if (p->dtype == GANET_BF16)
+    launch_pack_weight<bf16_t, bf16_t>(p, pl, weight, wp, s);
+  else
+    launch_pack_weight<f16_t, f16_t>(p, pl, weight, wp, s);
+  return ganet_check_launch();
+}
+}  // namespace
+
+extern "C" int ganet_deform_conv_pack_weight(const void *weight,
+                                             const ganet_dcn_params *p,
+                                             void *packed, size_t packed_bytes,
+                                             ganet_stream_t stream) {
+  if (!weight || !p || !packed) return GANET_ERR_NULL;
+  Plan pl;
+  const int rc = make_plan(p, &pl);
+  if (rc != GANET_OK) return rc;
+  if (packed_bytes < pl.wp_bytes) return GANET_ERR_WORKSPACE;
+  return pack_weight_dispatch(p, pl, weight, packed, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
@@ -538,13 +571,14 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
   // (deform_conv_cuda.cpp:127); the modules pad before calling (deform_conv.py:301-317)
   if (!mask && (p->H < p->kH || p->W < p->kW)) return GANET_ERR_BAD_SHAPE;
   if (bias && !mask) return GANET_ERR_BAD_SHAPE;  // DCNv1 has no bias (deform_conv.py:205)
-  if (workspace_bytes < pl.xh_bytes + pl.wp_bytes || !workspace)
+  const size_t need = pl.xh_bytes + (p->weight_is_packed ? 0 : pl.wp_bytes);
+  if (need > 0 && (workspace_bytes < need || !workspace))
     return GANET_ERR_WORKSPACE;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   void *xh = pl.copy_x ? static_cast<void *>(ws) : nullptr;
-  void *wp = ws + pl.xh_bytes;
+  const void *wp = p->weight_is_packed ? weight : static_cast<const void *>(ws + pl.xh_bytes);
 
   if (pl.copy_x) {
     if (p->dtype == GANET_F32 && pl.ta == GANET_F32)
@@ -557,15 +591,9 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
       launch_x_copy<f16_t, f16_t>(p, pl, x, xh, s);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
-  if (p->dtype == GANET_F32 && pl.ta == GANET_F32)
-    launch_pack_weight<float, float>(p, pl, weight, wp, s);
-  else if (p->dtype == GANET_F32 && pl.ta == GANET_BF16)
-    launch_pack_weight<float, bf16_t>(p, pl, weight, wp, s);
-  else if (p->dtype == GANET_BF16)
-    launch_pack_weight<bf16_t, bf16_t>(p, pl, weight, wp, s);
-  else
-    launch_pack_weight<f16_t, f16_t>(p, pl, weight, wp, s);
-  if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+  if (!p->weight_is_packed &&
+      pack_weight_dispatch(p, pl, weight, ws + pl.xh_bytes, s) != GANET_OK)
+    return GANET_ERR_HIP;
 
   DcnArgs a;
   a.xh = pl.copy_x ? xh : x;

@@ -29,6 +29,10 @@ class _Config(object):
     """mfma_bf16: contract float32 inputs on the bf16 matrix cores (fp32
     accumulate, ~1e-2 relative error) instead of the exact-fp32 MFMA."""
     mfma_bf16 = False
+    # Re-use the kernel-layout copy of a weight across calls while the tensor's
+    # (data_ptr, _version) is unchanged.  Off by default: writes through
+    # `weight.data` do not bump `_version`, so a stale copy could be used.
+    cache_packed_weights = False
 
 
 config = _Config()
@@ -37,6 +41,33 @@ config = _Config()
 def _is_channels_last(t):
     return (t.dim() == 4 and not t.is_contiguous()
             and t.is_contiguous(memory_format=torch.channels_last))
+
+
+_PACKED = {}          # (weight identity) -> packed device tensor
+_PACKED_MAX = 32
+
+
+def _packed_weight(L, weight, p):
+    """Weights repacked for the kernel ([tap][Cout][Cin]); cached while the
+    parameter is unchanged (inference: one pack per module, not per call)."""
+    key = (weight.data_ptr(), weight._version, weight.dtype, weight.device,
+           tuple(weight.shape), p.mfma_bf16, p.deformable_groups)
+    hit = _PACKED.get(key)
+    if hit is not None:
+        return hit
+    nbytes = L.ganet_deform_conv_packed_weight_bytes(ctypes.byref(p))
+    if nbytes == 0:
+        return None  # invalid / unsupported: let the forward call name the reason
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    stream = torch.cuda.current_stream(weight.device).cuda_stream
+    rc = L.ganet_deform_conv_pack_weight(weight.data_ptr(), ctypes.byref(p),
+                                         packed.data_ptr(), nbytes, stream)
+    _lib.check(rc, "ganet_deform_conv_pack_weight")
+    if len(_PACKED) >= _PACKED_MAX:
+        _PACKED.pop(next(iter(_PACKED)))
+    # keep the source tensor alive with its packed copy so data_ptr stays unique
+    _PACKED[key] = (packed, weight)
+    return _PACKED[key]
 
 
 def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
@@ -103,16 +134,20 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
     out = torch.empty((B, Cout, Ho, Wo), dtype=input.dtype, device=input.device,
                       memory_format=torch.channels_last if nhwc
                       else torch.contiguous_format)
-    ws_bytes = L.ganet_deform_conv_workspace_bytes(ctypes.byref(p))
-    if ws_bytes == 0:
-        # let the library name the reason
-        ws_bytes = 256
     with torch.cuda.device(input.device):
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
+        w_ptr = weight.data_ptr()
+        if config.cache_packed_weights and (
+                not weight.requires_grad or not torch.is_grad_enabled()):
+            packed = _packed_weight(L, weight.detach(), p)
+            if packed is not None:
+                p.weight_is_packed = 1
+                w_ptr = packed[0].data_ptr()
+        ws_bytes = L.ganet_deform_conv_workspace_bytes(ctypes.byref(p))
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=input.device)
         stream = torch.cuda.current_stream(input.device).cuda_stream
         rc = L.ganet_deform_conv_forward(
             input.data_ptr(), offset.data_ptr(),
-            mask.data_ptr() if mask is not None else None, weight.data_ptr(),
+            mask.data_ptr() if mask is not None else None, w_ptr,
             bias.data_ptr() if bias is not None else None, out.data_ptr(),
             ctypes.byref(p), ws.data_ptr(), ws_bytes, stream)
     if rc == _lib.GANET_ERR_BAD_SHAPE and mask is None and (H < kH or W < kW):

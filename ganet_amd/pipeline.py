@@ -1,0 +1,115 @@
+"""Allocation-free steady-state driver of the hot path for one GPU.
+
+`HotPath` owns every buffer the C-ABI needs (packed weights, workspaces, the
+LFA output, the decode output block and its pinned host mirror), so a serving
+loop - or bench.py - enqueues one step with no allocator traffic:
+
+    LFA   : feature = relu(DeformConv1D(x, pts - base))   (lanepoints_conv.py:170-172)
+    decode: NMS + compaction + grouping for the whole batch, then ONE async
+            D2H copy of the compact result block (ganet_head.py:203-238,
+            post_process.py:141-194)
+
+Images are independent: on N GPUs each rank owns a contiguous block of the
+batch and runs its own HotPath; nothing is exchanged between ranks.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .decode import DecodeBuffers, DecodeResult, _params
+
+
+class HotPath(object):
+
+    def __init__(self, B, H, W, Cin=256, Cout=64, K=7, dtype=torch.bfloat16,
+                 device=None, thr=0.4, root_thr=1.0, cluster_thr=5.0,
+                 by_center_thr=5.0, max_kpts=1024, max_centers=128,
+                 channels_last=True, mfma_bf16=False, fuse_relu=True,
+                 offset_is_points=True):
+        self.L = _lib.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.B, self.H, self.W, self.K = B, H, W, K
+        self.dtype = dtype
+        self.channels_last = channels_last
+        p = _lib.DcnParams()
+        p.B, p.Cin, p.H, p.W, p.Cout = B, Cin, H, W, Cout
+        p.kH, p.kW, p.sH, p.sW = 1, K, 1, 1
+        p.pH, p.pW, p.dH, p.dW = 0, (K - 1) // 2, 1, 1
+        p.groups = p.deformable_groups = 1
+        p.dtype = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+        p.x_layout = p.out_layout = 1 if channels_last else 0
+        p.mfma_bf16 = 1 if (mfma_bf16 and dtype == torch.float32) else 0
+        p.fuse_relu = 1 if fuse_relu else 0
+        p.offset_is_points = 1 if offset_is_points else 0
+        p.weight_is_packed = 1
+        self.p = p
+        with torch.cuda.device(self.device):
+            nb = self.L.ganet_deform_conv_packed_weight_bytes(ctypes.byref(p))
+            if nb == 0:
+                raise ValueError("unsupported LFA configuration")
+            self.packed = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            self.ws_bytes = self.L.ganet_deform_conv_workspace_bytes(ctypes.byref(p))
+            self.ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8,
+                                  device=self.device)
+            self.feature = torch.empty(
+                (B, Cout, H, W), dtype=dtype, device=self.device,
+                memory_format=torch.channels_last if channels_last
+                else torch.contiguous_format)
+            by_center = by_center_thr is not None
+            caps = (max_kpts, max_centers, max_centers if by_center else max_kpts)
+            self.dp = _params(B, H, W, thr, root_thr, cluster_thr, by_center_thr, caps)
+            self.bufs = DecodeBuffers(B, caps[0], caps[1], caps[2], self.device)
+            self.dws_bytes = self.L.ganet_decode_workspace_bytes(ctypes.byref(self.dp))
+            self.dws = torch.empty(max(self.dws_bytes, 256), dtype=torch.uint8,
+                                   device=self.device)
+            self.host = torch.empty(self.bufs.total, dtype=torch.int32,
+                                    pin_memory=True)
+        self.params = dict(thr=thr, root_thr=root_thr, cluster_thr=cluster_thr,
+                           by_center_thr=by_center_thr)
+        self._has_weight = False
+
+    def set_weight(self, weight):
+        """weight [Cout, Cin, 1, K] in the module's dtype; packed once."""
+        weight = weight.detach().to(device=self.device, dtype=self.dtype).contiguous()
+        q = _lib.DcnParams.from_buffer_copy(self.p)
+        q.weight_is_packed = 0
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.L.ganet_deform_conv_pack_weight(
+            weight.data_ptr(), ctypes.byref(q), self.packed.data_ptr(),
+            self.packed.numel(), stream)
+        _lib.check(rc, "ganet_deform_conv_pack_weight")
+        torch.cuda.current_stream(self.device).synchronize()
+        self._has_weight = True
+
+    def lfa(self, x, pts):
+        """Enqueue the LFA on the current stream; returns the (reused) output."""
+        assert self._has_weight, "call set_weight first"
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.L.ganet_deform_conv_forward(
+            x.data_ptr(), pts.data_ptr(), None, self.packed.data_ptr(), None,
+            self.feature.data_ptr(), ctypes.byref(self.p), self.ws.data_ptr(),
+            self.ws_bytes, stream)
+        _lib.check(rc, "ganet_deform_conv_forward")
+        return self.feature
+
+    def decode(self, heat, offset, error, copy_to_host=True):
+        """Enqueue decode + grouping (+ the async D2H of the result block)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.L.ganet_decode_batch(
+            heat.data_ptr(), offset.data_ptr(), error.data_ptr(),
+            ctypes.byref(self.dp), ctypes.byref(self.bufs.out),
+            self.dws.data_ptr(), self.dws_bytes, stream)
+        _lib.check(rc, "ganet_decode_batch")
+        if copy_to_host:
+            self.host.copy_(self.bufs.dev, non_blocking=True)
+
+    def step(self, x, pts, heat, offset, error):
+        self.lfa(x, pts)
+        self.decode(heat, offset, error)
+
+    def result(self):
+        """Wait for the stream and view the last step's decode result."""
+        torch.cuda.current_stream(self.device).synchronize()
+        views = self.bufs.host_views(self.host.numpy())
+        return DecodeResult(views, self.params, grouped=True)

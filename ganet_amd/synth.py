@@ -30,33 +30,39 @@ SHAPES = {
 }
 
 
-def lfa_inputs(B, Cin, H, W, K, Cout=64, seed=0, dtype=np.float32):
-    """x [B,Cin,H,W], dcn_offset [B,2K,H,W], weight [Cout,Cin,1,K], pts [B,2K,H,W].
-
-    `pts` is the LFA's point regression (y,x pairs, pixels relative to the
-    output location); `dcn_offset = pts - base` with base = [0,-p, 0,-p+1, ...]
-    (mmdet/models/dense_heads/lanepoints_conv.py:63-74,170).
-    """
+def lfa_points(B, H, W, K, seed=0):
+    """pts_out_init [B,2K,H,W] (y,x pairs, pixels relative to the output
+    location) and dcn_offset = pts - base with base = [0,-p, 0,-p+1, ...]
+    (mmdet/models/dense_heads/lanepoints_conv.py:63-74,170)."""
     p = (K - 1) // 2
-    xs, offs, ptss = [], [], []
+    base = np.zeros((2 * K, 1, 1), dtype=np.float32)
+    base[1::2, 0, 0] = np.arange(-p, p + 1, dtype=np.float32)
+    pts = np.empty((B, 2 * K, H, W), dtype=np.float32)
     for b in range(B):
-        rng = np.random.default_rng(seed + b)
-        x = rng.standard_normal((Cin, H, W), dtype=np.float32)
-        pts = np.empty((2 * K, H, W), dtype=np.float32)
+        rng = np.random.default_rng([seed + b, 1])
         for k in range(K):
-            pts[2 * k] = rng.normal(0.0, 1.5, (H, W))
-            pts[2 * k + 1] = ((k - p) * rng.uniform(0.5, 1.5, (H, W))
-                              + rng.normal(0.0, 0.5, (H, W)))
-        base = np.zeros((2 * K, 1, 1), dtype=np.float32)
-        base[1::2, 0, 0] = np.arange(-p, p + 1, dtype=np.float32)
-        xs.append(x)
-        ptss.append(pts)
-        offs.append(pts - base)
-    rng = np.random.default_rng(seed + 1000003)
+            pts[b, 2 * k] = rng.normal(0.0, 1.5, (H, W))
+            pts[b, 2 * k + 1] = ((k - p) * rng.uniform(0.5, 1.5, (H, W))
+                                 + rng.normal(0.0, 0.5, (H, W)))
+    return pts, pts - base[None]
+
+
+def lfa_weight(Cin, K, Cout=64, seed=0):
+    """weight [Cout,Cin,1,K] ~ U(+-1/sqrt(Cin*K))  (mmdet/ops/dcn/deform_conv.py:294-299)."""
+    rng = np.random.default_rng([seed, 2])
     bound = 1.0 / math.sqrt(Cin * K)
-    weight = rng.uniform(-bound, bound, (Cout, Cin, 1, K)).astype(np.float32)
-    return (np.stack(xs).astype(dtype), np.stack(offs).astype(np.float32),
-            weight.astype(dtype), np.stack(ptss).astype(np.float32))
+    return rng.uniform(-bound, bound, (Cout, Cin, 1, K)).astype(np.float32)
+
+
+def lfa_inputs(B, Cin, H, W, K, Cout=64, seed=0, dtype=np.float32):
+    """x [B,Cin,H,W], dcn_offset [B,2K,H,W], weight [Cout,Cin,1,K], pts [B,2K,H,W]."""
+    x = np.empty((B, Cin, H, W), dtype=np.float32)
+    for b in range(B):
+        x[b] = np.random.default_rng([seed + b, 0]).standard_normal(
+            (Cin, H, W), dtype=np.float32)
+    pts, off = lfa_points(B, H, W, K, seed)
+    weight = lfa_weight(Cin, K, Cout, seed)
+    return x.astype(dtype), off, weight.astype(dtype), pts
 
 
 def decode_inputs(B, H, W, lanes=4, seed=0, noise=0.05):

@@ -85,7 +85,10 @@ typedef struct {
                                kernel subtracts the kernel-grid base itself
                                (lanepoints_conv.py:63-74,170); needs kH == 1,
                                dW == 1, pW == (kW-1)/2 */
-  int32_t reserved[3];
+  int32_t weight_is_packed; /* 1 = `weight` was produced by
+                               ganet_deform_conv_pack_weight for these params
+                               (inference: pack once, not per call) */
+  int32_t reserved[2];
 } ganet_dcn_params;
 
 /* Output spatial size rule of the reference
@@ -96,6 +99,16 @@ int ganet_dcn_out_size(int in, int pad, int dilation, int k, int stride);
  * (channel-last copy of x when x_layout is NCHW, repacked weights).
  * Returns 0 for invalid parameters. */
 size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p);
+
+/* Weight pre-packing (no counterpart in the reference, which hands the raw
+ * [Cout,Cin,kH,kW] tensor to cuBLAS on every call, deform_conv_cuda.cpp:228-236):
+ * the fused kernel reads weights as [tap][Cout][Cin] in its arithmetic dtype.
+ * ganet_deform_conv_forward packs into its workspace on every call unless
+ * p->weight_is_packed is set and `weight` points at a buffer filled here. */
+size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p);
+int ganet_deform_conv_pack_weight(const void *weight, const ganet_dcn_params *p,
+                                  void *packed, size_t packed_bytes,
+                                  ganet_stream_t stream);
 
 /* x      [B,Cin,H,W]  (or NHWC bytes when x_layout == GANET_NHWC), p->dtype
  * offset [B, 2*dg*kH*kW, Hout, Wout] float32, channel 2t = dy, 2t+1 = dx of tap t
