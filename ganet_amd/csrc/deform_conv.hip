@@ -69,10 +69,75 @@ __device__ __forceinline__ f16_t from_f32<f16_t>(float v) {
   return (f16_t)v;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define GANET_GLOBAL __attribute__((address_space(1)))
+
+// Pointers that reach a kernel inside a by-value struct are generic ("flat") to
+// the compiler; these casts give it global_load/global_store_dwordx4.
+__device__ __forceinline__ u32x4 ldg128(const void *p) {
+  return *(const GANET_GLOBAL u32x4 *)(p);
+}
+__device__ __forceinline__ float ldg_f32(const float *p) {
+  return *(const GANET_GLOBAL float *)(p);
+}
+
+// 16-byte piece <-> floats
+template <typename TA>
+struct PieceCvt;
+template <>
+struct PieceCvt<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void unpack(const u32x4 &u, float *f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(u[i]);
+  }
+  __device__ static __forceinline__ u32x4 pack(const float *f) {
+    u32x4 u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = __float_as_uint(f[i]);
+    return u;
+  }
+};
+template <>
+struct PieceCvt<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void unpack(const u32x4 &u, float *f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(u[i] << 16);
+      f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ u32x4 pack(const float *f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];  // RNE, NaN-preserving
+    return __builtin_bit_cast(u32x4, v);
+  }
+};
+template <>
+struct PieceCvt<f16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void unpack(const u32x4 &u, float *f) {
+    const f16x8 v = __builtin_bit_cast(f16x8, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
+  __device__ static __forceinline__ u32x4 pack(const float *f) {
+    f16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (_Float16)f[i];
+    return __builtin_bit_cast(u32x4, v);
+  }
+};
+
 constexpr int TM = 128;       // output pixels per workgroup
 constexpr int TN = 64;        // output channels per workgroup
-constexpr int NTHREADS = 256;
+constexpr int NTHREADS = 512; // 8 wavefronts: 4 pixel blocks x 2 output halves
 constexpr int CHUNK_BYTES_MAX = 256;
+constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond any buffer window: reads 0
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct DcnArgs {
   const void *xh;       // NHWC feature map, Cp channels per pixel
@@ -98,7 +163,6 @@ struct Mma<float> {
   // lane (i = l&31, h = l>>5) supplies A[i][k=h] and B[k=h][j=i]; with the lane
   // reading channels [8q+4h, 8q+4h+4) of its row, step m contracts channels
   // 8q+m (h=0) and 8q+4+m (h=1) on both operands alike.
-  static constexpr int EPL = 4;
   typedef f32x4 frag;
   __device__ static __forceinline__ void mma(const frag &a, const frag &b,
                                              f32x16 &c) {
@@ -111,7 +175,6 @@ struct Mma<float> {
 template <>
 struct Mma<bf16_t> {
   // 16 B = 8 bf16 per lane: lane (r, h) holds A[r][8h+j], B[8h+j][r], j = 0..7.
-  static constexpr int EPL = 8;
   typedef bf16x8 frag;
   __device__ static __forceinline__ void mma(const frag &a, const frag &b,
                                              f32x16 &c) {
@@ -121,7 +184,6 @@ struct Mma<bf16_t> {
 
 template <>
 struct Mma<f16_t> {
-  static constexpr int EPL = 8;
   typedef f16x8 frag;
   __device__ static __forceinline__ void mma(const frag &a, const frag &b,
                                              f32x16 &c) {
@@ -129,23 +191,95 @@ struct Mma<f16_t> {
   }
 };
 
-// 16-byte piece of EPL elements
+// Bilinear blend of four 16-byte pieces (one per corner) with per-pixel weights,
+// two channels per instruction (v_pk_mul/fma_f32).
+//   w1*v1 + w2*v2 + w3*v3 + w4*v4   (deform_conv_cuda_kernel.cu:111-113), * mask (:627)
 template <typename TA>
-struct alignas(16) Piece {
-  TA e[16 / sizeof(TA)];
+struct Blend;
+
+template <>
+struct Blend<float> {
+  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w,
+                                              bool has_mask, float mk) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x2 a = {__uint_as_float(v[0][2 * i]), __uint_as_float(v[0][2 * i + 1])};
+      f32x2 b = {__uint_as_float(v[1][2 * i]), __uint_as_float(v[1][2 * i + 1])};
+      f32x2 c = {__uint_as_float(v[2][2 * i]), __uint_as_float(v[2][2 * i + 1])};
+      f32x2 d = {__uint_as_float(v[3][2 * i]), __uint_as_float(v[3][2 * i + 1])};
+      f32x2 r = a * w.x;
+      r = b * w.y + r;
+      r = c * w.z + r;
+      r = d * w.w + r;
+      if (has_mask) r = r * mk;
+      o[2 * i] = __float_as_uint(r.x);
+      o[2 * i + 1] = __float_as_uint(r.y);
+    }
+    return o;
+  }
+};
+
+template <>
+struct Blend<bf16_t> {
+  __device__ static __forceinline__ f32x2 up(unsigned int u) {
+    f32x2 r = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+    return r;
+  }
+  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w,
+                                              bool has_mask, float mk) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x2 r = up(v[0][i]) * w.x;
+      r = up(v[1][i]) * w.y + r;
+      r = up(v[2][i]) * w.z + r;
+      r = up(v[3][i]) * w.w + r;
+      if (has_mask) r = r * mk;
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const bf16x2 p = {(__bf16)r.x, (__bf16)r.y};  // v_cvt_pk_bf16_f32: RNE, NaN kept
+      o[i] = __builtin_bit_cast(unsigned int, p);
+    }
+    return o;
+  }
+};
+
+template <>
+struct Blend<f16_t> {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  __device__ static __forceinline__ f32x2 up(unsigned int u) {
+    const f16x2 h = __builtin_bit_cast(f16x2, u);
+    f32x2 r = {(float)h.x, (float)h.y};
+    return r;
+  }
+  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w,
+                                              bool has_mask, float mk) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x2 r = up(v[0][i]) * w.x;
+      r = up(v[1][i]) * w.y + r;
+      r = up(v[2][i]) * w.z + r;
+      r = up(v[3][i]) * w.w + r;
+      if (has_mask) r = r * mk;
+      const f16x2 p = {(_Float16)r.x, (_Float16)r.y};
+      o[i] = __builtin_bit_cast(unsigned int, p);
+    }
+    return o;
+  }
 };
 
 template <typename TA, typename TO, int KC>
-__global__ __launch_bounds__(NTHREADS, 2) void dcn_fused_kernel(DcnArgs a) {
+__global__ __launch_bounds__(NTHREADS, 4) void dcn_fused_kernel(DcnArgs a) {
   constexpr int EPL = 16 / sizeof(TA);          // elements per 16-B piece
   constexpr int LPP = KC / EPL;                 // lanes (pieces) per pixel chunk
   constexpr int PPP = NTHREADS / LPP;           // pixels per gather pass
   constexpr int NPASS = TM / PPP;
   constexpr int LDA = KC + EPL;                 // padded row (elements): +16 B
-  constexpr int GROUP = NPASS < 4 ? NPASS : 4;  // passes with loads in flight
+  constexpr int GROUP = NPASS < 2 ? NPASS : 2;  // passes per load group
+  constexpr int NGROUP = NPASS / GROUP;
   static_assert(KC * sizeof(TA) <= CHUNK_BYTES_MAX, "chunk too wide");
-  static_assert(NPASS % GROUP == 0, "pass grouping");
-  typedef Piece<TA> piece_t;
+  static_assert(NPASS >= 1 && NPASS % GROUP == 0, "pass grouping");
   typedef typename Mma<TA>::frag frag_t;
 
   constexpr int A_BYTES = TM * LDA * sizeof(TA);
@@ -153,9 +287,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void dcn_fused_kernel(DcnArgs a) {
   constexpr int C_BYTES = TN * (TM + 1) * 4;    // NCHW epilogue transpose
   constexpr int AB_BYTES = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[AB_BYTES];
-  __shared__ int s_pix[TM];
-  __shared__ float s_w[4][TM];
-  __shared__ int s_flags[TM];
+  // per output pixel of the tile, for the current (tap, deformable group): byte
+  // offsets of the four bilinear corners inside this tile's buffer window
+  // (OOB_OFFSET = corner outside the map: the buffer load returns 0, which is the
+  // reference's `v = 0`) and the four bilinear weights
+  __shared__ __attribute__((aligned(16))) unsigned int s_off[TM][4];
+  __shared__ __attribute__((aligned(16))) float s_w[TM][4];
   __shared__ float s_mask[TM];
 
   TA *As = reinterpret_cast<TA *>(smem);
@@ -163,22 +300,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void dcn_fused_kernel(DcnArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
-  const long long tile = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs
+  // (blocks b and b+8 share an L2), so give each XCD one contiguous range of
+  // tiles - consecutive tiles sample the same image rows, whose re-reads then hit
+  // that XCD's L2.  Bijective for any grid size; placement only affects speed.
+  long long tile;
+  {
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    tile = (long long)(xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
   const int n0 = blockIdx.y * TN;
   const int HWo = a.Ho * a.Wo;
   const int T = a.kH * a.kW;
-  const TA *xh = static_cast<const TA *>(a.xh);
   const TA *wp = static_cast<const TA *>(a.wp);
 
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    acc0[i] = 0.f;
-    acc1[i] = 0.f;
-  }
+  // Buffer window of this tile: starts at the first image the tile touches and is
+  // clamped below 2 GiB, so 32-bit offsets address it and OOB_OFFSET is outside.
+  const int b0 = (int)((tile * TM) / HWo);
+  const size_t img_bytes = (size_t)a.H * a.W * a.Cp * sizeof(TA);
+  const size_t win_rest = (size_t)(a.B - b0) * img_bytes;
+  const unsigned win_bytes = win_rest < 0x7fffffffull ? (unsigned)win_rest : 0x7fffffffu;
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char *>(static_cast<const unsigned char *>(a.xh)) +
+          (size_t)b0 * img_bytes,
+      0, (int)win_bytes, 0x00020000);
 
-  const int lp = tid % LPP;  // piece within the pixel chunk
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  const int lp = tid % LPP;  // 16-B piece within the pixel chunk
   const int pr = tid / LPP;  // pixel within the pass
+  const bool has_mask = a.mask != nullptr;
 
   for (int t = 0; t < T; ++t) {
     const int ti = t / a.kW, tj = t - ti * a.kW;
@@ -186,7 +340,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dcn_fused_kernel(DcnArgs a) {
       __syncthreads();  // previous readers of the coordinate table are done
       if (tid < TM) {
         const long long p = tile * TM + tid;
-        int flags = 0, pix = 0;
+        unsigned c1 = OOB_OFFSET, c2 = OOB_OFFSET, c3 = OOB_OFFSET, c4 = OOB_OFFSET;
         float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 1.f;
         if (p < a.P) {
           const int b = (int)(p / HWo);
@@ -194,8 +348,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void dcn_fused_kernel(DcnArgs a) {
           const int ho = hw / a.Wo, wo = hw - ho * a.Wo;
           const float *op = a.offset +
                             ((size_t)(b * a.dg + g) * 2 * T + 2 * t) * HWo + hw;
-          float off_h = op[0];
-          float off_w = op[HWo];
+          float off_h = ldg_f32(op);
+          float off_w = ldg_f32(op + HWo);
           if (a.points)  // dcn_offset = pts - base  (lanepoints_conv.py:63-74,170)
             off_w = off_w - (float)(tj - a.pW);
           const float h_im = (float)(ho * a.sH - a.pH + ti * a.dH) + off_h;
@@ -209,21 +363,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void dcn_fused_kernel(DcnArgs a) {
             w2 = hh * lw;
             w3 = lh * hw_;
             w4 = lh * lw;
-            if (h_low >= 0 && w_low >= 0) flags |= 1;
-            if (h_low >= 0 && w_high <= a.W - 1) flags |= 2;
-            if (h_high <= a.H - 1 && w_low >= 0) flags |= 4;
-            if (h_high <= a.H - 1 && w_high <= a.W - 1) flags |= 8;
-            pix = (b * a.H + h_low) * a.W + w_low;
+            const unsigned px = (unsigned)(a.Cp * sizeof(TA));      // bytes per pixel
+            const unsigned row = (unsigned)a.W * px;
+            const unsigned base = (unsigned)(b - b0) * (unsigned)img_bytes +
+                                  (unsigned)h_low * row + (unsigned)w_low * px;
+            const bool hl = h_low >= 0, hh_ok = h_high <= a.H - 1;
+            const bool wl = w_low >= 0, wh_ok = w_high <= a.W - 1;
+            if (hl && wl) c1 = base;
+            if (hl && wh_ok) c2 = base + px;
+            if (hh_ok && wl) c3 = base + row;
+            if (hh_ok && wh_ok) c4 = base + row + px;
           }
-          if (a.mask)
-            mk = a.mask[((size_t)(b * a.dg + g) * T + t) * HWo + hw];
+          if (has_mask)
+            mk = ldg_f32(a.mask + ((size_t)(b * a.dg + g) * T + t) * HWo + hw);
         }
-        s_pix[tid] = pix;
-        s_w[0][tid] = w1;
-        s_w[1][tid] = w2;
-        s_w[2][tid] = w3;
-        s_w[3][tid] = w4;
-        s_flags[tid] = flags;
+        *reinterpret_cast<uint4 *>(s_off[tid]) = make_uint4(c1, c2, c3, c4);
+        *reinterpret_cast<float4 *>(s_w[tid]) = make_float4(w1, w2, w3, w4);
         s_mask[tid] = mk;
       }
       __syncthreads();
@@ -236,61 +391,61 @@ __global__ __launch_bounds__(NTHREADS, 2) void dcn_fused_kernel(DcnArgs a) {
 #pragma unroll
           for (int q = tid; q < PIECES; q += NTHREADS) {
             const int row = q / LPP, pc = q - row * LPP;
-            const piece_t v = *reinterpret_cast<const piece_t *>(
+            const u32x4 v = ldg128(
                 wp + ((size_t)(t * a.CoutP + n0 + row) * a.Cp + c0 + pc * EPL));
-            *reinterpret_cast<piece_t *>(Bs + row * LDA + pc * EPL) = v;
+            *reinterpret_cast<u32x4 *>(Bs + row * LDA + pc * EPL) = v;
           }
         }
         // ---- gather + blend the A chunk [TM][KC] --------------------------
+        // 16 lanes x 16 B read one pixel's 256-B channel run per corner; the loads
+        // are unconditional buffer loads (no branches, no waits between them) and
+        // the next group's loads are issued before the current group is blended.
+        const unsigned lane_off = (unsigned)((c0 + lp * EPL) * sizeof(TA));
+        u32x4 v[2][GROUP][4];
+        uint4 cx[2][GROUP];
 #pragma unroll
-        for (int pg = 0; pg < NPASS; pg += GROUP) {
-          piece_t v[GROUP][4];
-          int fl[GROUP];
+        for (int u = 0; u < GROUP; ++u) {
+          cx[0][u] = *reinterpret_cast<const uint4 *>(s_off[u * PPP + pr]);
+          v[0][u][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[0][u].x + lane_off, 0, 0);
+          v[0][u][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[0][u].y + lane_off, 0, 0);
+          v[0][u][2] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[0][u].z + lane_off, 0, 0);
+          v[0][u][3] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[0][u].w + lane_off, 0, 0);
+        }
 #pragma unroll
-          for (int u = 0; u < GROUP; ++u) {
-            const int r = (pg + u) * PPP + pr;
-            const int f = s_flags[r];
-            fl[u] = f;
-            const TA *base = xh + (size_t)(long long)s_pix[r] * a.Cp + c0 + lp * EPL;
-            const piece_t zero = {};
-            v[u][0] = (f & 1) ? *reinterpret_cast<const piece_t *>(base) : zero;
-            v[u][1] = (f & 2) ? *reinterpret_cast<const piece_t *>(base + a.Cp) : zero;
-            v[u][2] = (f & 4) ? *reinterpret_cast<const piece_t *>(base + (size_t)a.W * a.Cp) : zero;
-            v[u][3] = (f & 8) ? *reinterpret_cast<const piece_t *>(base + (size_t)(a.W + 1) * a.Cp) : zero;
+        for (int gi = 0; gi < NGROUP; ++gi) {
+          const int cur = gi & 1, nxt = cur ^ 1;
+          if (gi + 1 < NGROUP) {
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) {
+              const int r = ((gi + 1) * GROUP + u) * PPP + pr;
+              cx[nxt][u] = *reinterpret_cast<const uint4 *>(s_off[r]);
+              v[nxt][u][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[nxt][u].x + lane_off, 0, 0);
+              v[nxt][u][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[nxt][u].y + lane_off, 0, 0);
+              v[nxt][u][2] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[nxt][u].z + lane_off, 0, 0);
+              v[nxt][u][3] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[nxt][u].w + lane_off, 0, 0);
+            }
           }
 #pragma unroll
           for (int u = 0; u < GROUP; ++u) {
-            const int r = (pg + u) * PPP + pr;
-            const float w1 = s_w[0][r], w2 = s_w[1][r], w3 = s_w[2][r], w4 = s_w[3][r];
-            const float mk = s_mask[r];
-            piece_t o;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-              // w1*v1 + w2*v2 + w3*v3 + w4*v4   (deform_conv_cuda_kernel.cu:111-113)
-              float val = w1 * to_f32(v[u][0].e[e]);
-              val = fmaf(w2, to_f32(v[u][1].e[e]), val);
-              val = fmaf(w3, to_f32(v[u][2].e[e]), val);
-              val = fmaf(w4, to_f32(v[u][3].e[e]), val);
-              if (a.mask) val = val * mk;  // :627
-              o.e[e] = from_f32<TA>(val);
-            }
-            *reinterpret_cast<piece_t *>(As + r * LDA + lp * EPL) = o;
+            const int r = (gi * GROUP + u) * PPP + pr;
+            const float4 w = *reinterpret_cast<const float4 *>(s_w[r]);
+            const float mk = has_mask ? s_mask[r] : 1.f;
+            const u32x4 o = Blend<TA>::run(v[cur][u], w, has_mask, mk);
+            *reinterpret_cast<u32x4 *>(As + r * LDA + lp * EPL) = o;
           }
         }
         __syncthreads();
-        // ---- contract: wavefront `wid` x (2 x 32 outputs) -----------------
+        // ---- contract: wavefront = 32 pixels x 32 outputs ------------------
         {
           const int i = lane & 31, h = lane >> 5;
-          const TA *arow = As + (wid * 32 + i) * LDA + h * EPL;
-          const TA *brow0 = Bs + i * LDA + h * EPL;
-          const TA *brow1 = Bs + (32 + i) * LDA + h * EPL;
+          const int pb = wid & 3, nb = wid >> 2;
+          const TA *arow = As + (pb * 32 + i) * LDA + h * EPL;
+          const TA *brow = Bs + (nb * 32 + i) * LDA + h * EPL;
 #pragma unroll
           for (int q = 0; q < KC / (2 * EPL); ++q) {
             const frag_t fa = *reinterpret_cast<const frag_t *>(arow + q * 2 * EPL);
-            const frag_t fb0 = *reinterpret_cast<const frag_t *>(brow0 + q * 2 * EPL);
-            const frag_t fb1 = *reinterpret_cast<const frag_t *>(brow1 + q * 2 * EPL);
-            Mma<TA>::mma(fa, fb0, acc0);
-            Mma<TA>::mma(fa, fb1, acc1);
+            const frag_t fb = *reinterpret_cast<const frag_t *>(brow + q * 2 * EPL);
+            Mma<TA>::mma(fa, fb, acc);
           }
         }
         __syncthreads();
@@ -303,33 +458,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void dcn_fused_kernel(DcnArgs a) {
   TO *out = static_cast<TO *>(a.out);
   const TO *bias = static_cast<const TO *>(a.bias);
   const int col = lane & 31, half = lane >> 5;
-  float bias0 = 0.f, bias1 = 0.f;
-  if (bias) {
-    if (n0 + col < a.Cout) bias0 = to_f32(bias[n0 + col]);
-    if (n0 + 32 + col < a.Cout) bias1 = to_f32(bias[n0 + 32 + col]);
-  }
+  const int pb = wid & 3, nb = wid >> 2;
+  const int oc = n0 + nb * 32 + col;
+  float bias0 = 0.f;
+  if (bias && oc < a.Cout) bias0 = to_f32(bias[oc]);
   if (a.out_nhwc) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const long long p = tile * TM + wid * 32 + row;
-      if (p < a.P) {
-        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-        if (a.relu) {
-          v0 = fmaxf(v0, 0.f);
-          v1 = fmaxf(v1, 0.f);
-        }
-        if (n0 + col < a.Cout) out[p * a.Cout + n0 + col] = from_f32<TO>(v0);
-        if (n0 + 32 + col < a.Cout) out[p * a.Cout + n0 + 32 + col] = from_f32<TO>(v1);
+      const long long p = tile * TM + pb * 32 + row;
+      if (p < a.P && oc < a.Cout) {
+        float v0 = acc[r] + bias0;
+        if (a.relu) v0 = fmaxf(v0, 0.f);
+        out[p * a.Cout + oc] = from_f32<TO>(v0);
       }
     }
   } else {
     float *Cs = reinterpret_cast<float *>(smem);  // [TN][TM+1]; A/B are dead
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      Cs[col * (TM + 1) + row] = acc0[r] + bias0;
-      Cs[(32 + col) * (TM + 1) + row] = acc1[r] + bias1;
+      const int row = pb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      Cs[(nb * 32 + col) * (TM + 1) + row] = acc[r] + bias0;
     }
     __syncthreads();
     for (int idx = tid; idx < TN * TM; idx += NTHREADS) {
@@ -405,6 +554,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(
 
 struct Plan {
   int Ho, Wo, T;
+  int ta_dummy;
   int ta;        // arithmetic / LDS element type (ganet_dtype)
   int kc;        // channel chunk (elements)
   int Cp, CoutP;
@@ -442,6 +592,7 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
       (long long)p->B * pl->Ho * pl->Wo >= (1ll << 31))
     return GANET_ERR_UNSUPPORTED;
   pl->T = p->kH * p->kW;
+  pl->ta_dummy = 0;
   pl->ta = (p->dtype == GANET_F32 && p->mfma_bf16) ? GANET_BF16 : p->dtype;
   const int kc_big = pl->ta == GANET_F32 ? 64 : 128;
   const int kc_small = kc_big / 2;
@@ -459,6 +610,14 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
     return GANET_ERR_UNSUPPORTED;  // padded channels would straddle groups
   }
   pl->CoutP = (int)ganet_align_up((size_t)p->Cout, (size_t)TN);
+  {
+    // a tile's 32-bit buffer window spans every image the tile touches and must
+    // stay below 2 GiB (see OOB_OFFSET in the kernel)
+    const unsigned long long img_bytes =
+        (unsigned long long)p->H * p->W * pl->Cp * dtype_size(pl->ta);
+    const unsigned long long span = (unsigned long long)TM / ((unsigned long long)pl->Ho * pl->Wo) + 2;
+    if (img_bytes * span >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
+  }
   pl->copy_x = p->x_layout != GANET_NHWC || pl->Cp != p->Cin || pl->ta != p->dtype;
   pl->xh_bytes = pl->copy_x ? ganet_align_up((size_t)p->B * p->H * p->W * pl->Cp *
                                                  dtype_size(pl->ta), 256)
