@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--overlap-copy", action="store_true",
+                    help="copy the lane lists D2H on a second stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,7 +185,7 @@ def main():
     hp = HotPath(B, H, W, Cin=Cin, Cout=64, K=K, dtype=TORCH_DTYPE[dtype], device=dev,
                  thr=cfg["thr"], root_thr=cfg["root_thr"], cluster_thr=T, by_center_thr=T,
                  max_kpts=min(H * W, 4096 if cfg["lanes"] > 4 else 1024),
-                 max_centers=256)
+                 max_centers=256, overlap_copy=args.overlap_copy)
     hp.set_weight(d["w"])
 
     def one_step(ev=None):
@@ -201,7 +203,7 @@ def main():
         one_step()
     torch.cuda.synchronize()
     if wl["decode"]:
-        over = int(np.bitwise_or.reduce(hp.result().v["counts"][:, 3]))
+        over = int(np.bitwise_or.reduce(hp.result().counts[:, 3]))
         if over:
             raise SystemExit("decode capacity overflow in the bench configuration")
 
@@ -213,7 +215,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(events[i])
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()          # all streams of the device, copies included
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0

@@ -26,6 +26,7 @@ EXPORTS = (
     "ganet_deform_conv_workspace_bytes", "ganet_deform_conv_forward",
     "ganet_deform_conv_packed_weight_bytes", "ganet_deform_conv_pack_weight",
     "ganet_decode_workspace_bytes", "ganet_decode_batch", "ganet_group_batch",
+    "ganet_decode_pack",
 )
 
 
@@ -99,6 +100,10 @@ def lib():
         L.ganet_group_batch.restype = ctypes.c_int
         L.ganet_group_batch.argtypes = [ctypes.POINTER(DecodeParams),
                                         ctypes.POINTER(DecodeOut), ctypes.c_void_p]
+        L.ganet_decode_pack.restype = ctypes.c_int
+        L.ganet_decode_pack.argtypes = [ctypes.POINTER(DecodeParams),
+                                       ctypes.POINTER(DecodeOut), ctypes.c_void_p,
+                                       ctypes.c_size_t, ctypes.c_void_p]
         if L.ganet_abi_version() != 1:
             raise RuntimeError("ganet_amd: ABI version mismatch")
         _lib = L

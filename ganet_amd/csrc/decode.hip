@@ -345,7 +345,99 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
   }
 }
 
+// Compacts the capacity-strided per-image arrays into one dense record stream so
+// that the host copy moves only what was found:
+//   packed = [header B x 8][record 0][record 1]...
+//   header[b] = {n_kpts, n_centers, n_groups, overflow, record offset (words,
+//                from the end of the header), record words, total words (b == 0
+//                only), 0}
+//   record = kpt_xy[2nk] align[2nk] root[2nk] kpt_gid[nk] centers[2nc]
+//            center_gid[nc] group_center[2ngc] group_count[ng]
+// with nk/nc/ng clamped to the capacities and ngc = ng in by-centre mode, else 0.
+__device__ __forceinline__ int record_words(const int32_t *c, int max_k, int max_c,
+                                            int max_g, bool by_center, int *nk,
+                                            int *nc, int *ng) {
+  *nk = min(c[0], max_k);
+  *nc = min(c[1], max_c);
+  *ng = min(c[2], max_g);
+  return 7 * *nk + 3 * *nc + (by_center ? 2 * *ng : 0) + *ng;
+}
+
+__global__ __launch_bounds__(kBlock) void decode_pack_kernel(
+    ganet_decode_out o, int B, int max_k, int max_c, int max_g, int by_center,
+    int32_t *__restrict__ packed, long long packed_words) {
+  __shared__ int wave_sums[kWavesPerBlock];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int nk, nc, ng;
+  int part = 0;
+  for (int i = tid; i < b; i += kBlock)
+    part += record_words(o.counts + (size_t)i * GANET_DECODE_COUNT_STRIDE, max_k, max_c,
+                         max_g, by_center, &nk, &nc, &ng);
+  int off;
+  block_excl_scan(part, wave_sums, &off);  // off = total of the partial sums
+  const int32_t *c = o.counts + (size_t)b * GANET_DECODE_COUNT_STRIDE;
+  const int words = record_words(c, max_k, max_c, max_g, by_center, &nk, &nc, &ng);
+  const int ngc = by_center ? ng : 0;
+  int32_t *hdr = packed + (size_t)b * 8;
+  const long long rec0 = (long long)B * 8 + off;
+  const bool fits = rec0 + words <= packed_words;
+  if (tid == 0) {
+    hdr[0] = c[0];
+    hdr[1] = c[1];
+    hdr[2] = c[2];
+    hdr[3] = c[3] | (fits ? 0 : 8);
+    hdr[4] = off;
+    hdr[5] = words;
+    if (b != 0) hdr[6] = 0;
+    hdr[7] = 0;
+    if (b == B - 1) packed[6] = off + words;
+  }
+  if (!fits) return;
+  int32_t *r = packed + rec0;
+  const int32_t *kxy = o.kpt_xy + (size_t)b * max_k * 2;
+  const int32_t *al = reinterpret_cast<const int32_t *>(o.kpt_align) + (size_t)b * max_k * 2;
+  const int32_t *rt = reinterpret_cast<const int32_t *>(o.kpt_root) + (size_t)b * max_k * 2;
+  const int32_t *kg = o.kpt_gid + (size_t)b * max_k;
+  const int32_t *cxy = o.centers_xy + (size_t)b * max_c * 2;
+  const int32_t *cg = o.center_gid + (size_t)b * max_c;
+  const int32_t *gc = o.group_center + (size_t)b * max_g * 2;
+  const int32_t *gn = o.group_count + (size_t)b * max_g;
+  for (int i = tid; i < 2 * nk; i += kBlock) {
+    r[i] = kxy[i];
+    r[2 * nk + i] = al[i];
+    r[4 * nk + i] = rt[i];
+  }
+  r += 6 * nk;
+  for (int i = tid; i < nk; i += kBlock) r[i] = kg[i];
+  r += nk;
+  for (int i = tid; i < 2 * nc; i += kBlock) r[i] = cxy[i];
+  r += 2 * nc;
+  for (int i = tid; i < nc; i += kBlock) r[i] = cg[i];
+  r += nc;
+  for (int i = tid; i < 2 * ngc; i += kBlock) r[i] = gc[i];
+  r += 2 * ngc;
+  for (int i = tid; i < ng; i += kBlock) r[i] = gn[i];
+}
+
 }  // namespace
+
+extern "C" int ganet_decode_pack(const ganet_decode_params *p,
+                                 const ganet_decode_out *out, int32_t *packed,
+                                 size_t packed_words, ganet_stream_t stream) {
+  if (!p || !out || !packed) return GANET_ERR_NULL;
+  if (!out->counts || !out->centers_xy || !out->center_gid || !out->kpt_xy ||
+      !out->kpt_align || !out->kpt_root || !out->kpt_gid || !out->group_center ||
+      !out->group_count)
+    return GANET_ERR_NULL;
+  if (p->B <= 0 || p->max_kpts <= 0 || p->max_centers <= 0 || p->max_groups <= 0)
+    return GANET_ERR_BAD_SHAPE;
+  if (packed_words < (size_t)p->B * 8) return GANET_ERR_WORKSPACE;
+  hipLaunchKernelGGL(decode_pack_kernel, dim3(p->B), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), *out, p->B, p->max_kpts,
+                     p->max_centers, p->max_groups, p->by_center_thr >= 0 ? 1 : 0,
+                     packed, (long long)packed_words);
+  return ganet_check_launch();
+}
 
 extern "C" size_t ganet_decode_workspace_bytes(const ganet_decode_params *p) {
   if (!p || p->B <= 0 || p->H <= 0 || p->W <= 0) return 0;

@@ -131,9 +131,8 @@ struct PieceCvt<f16_t> {
   }
 };
 
-constexpr int TM = 128;       // output pixels per workgroup
 constexpr int TN = 64;        // output channels per workgroup
-constexpr int NTHREADS = 512; // 8 wavefronts: 4 pixel blocks x 2 output halves
+constexpr int TM_MAX = 256;   // largest pixel tile of a workgroup (8 waves x 32)
 constexpr int CHUNK_BYTES_MAX = 256;
 constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond any buffer window: reads 0
 
@@ -269,41 +268,61 @@ struct Blend<f16_t> {
   }
 };
 
-template <typename TA, typename TO, int KC>
-__global__ __launch_bounds__(NTHREADS, 4) void dcn_fused_kernel(DcnArgs a) {
-  constexpr int EPL = 16 / sizeof(TA);          // elements per 16-B piece
-  constexpr int LPP = KC / EPL;                 // lanes (pieces) per pixel chunk
-  constexpr int PPP = NTHREADS / LPP;           // pixels per gather pass
-  constexpr int NPASS = TM / PPP;
-  constexpr int LDA = KC + EPL;                 // padded row (elements): +16 B
-  constexpr int GROUP = NPASS < 2 ? NPASS : 2;  // passes per load group
+// Compiler-level ordering point for LDS traffic that stays inside one wavefront
+// (the hardware executes a wave's LDS operations in order).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One workgroup = NW wavefronts; every wavefront owns 32 output pixels x 64 output
+// channels end to end (coordinates, gather, blend, its private A tile in LDS, two
+// 32x32 accumulators).  Only the weight chunk is shared: it is double-buffered in
+// LDS and changes once per tap (bf16/f16: 256 channels) or half tap (fp32: 128),
+// which is the only workgroup barrier in the loop.  The gather is software
+// pipelined one step (16 buffer loads per lane-group) ahead of the blend, across
+// chunk and tap boundaries, so the memory pipe stays busy while a wave blends,
+// writes LDS and issues its MFMAs.
+template <typename TA, typename TO, int KCB, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
+  constexpr int ES = sizeof(TA);
+  constexpr int EPL = 16 / ES;                          // elements per 16-B piece
+  constexpr int KC = (KCB * ES > 256) ? 256 / ES : KCB; // gather chunk (elements)
+  constexpr int NSUB = KCB / KC;                        // gather chunks per weight chunk
+  constexpr int LPP = KC / EPL;                         // lanes per pixel chunk
+  constexpr int PPL = 64 / LPP;                         // pixels per load instruction
+  constexpr int NPASS = 32 / PPL;                       // load passes per gather chunk
+  constexpr int GROUP = NPASS >= 4 ? 4 : NPASS;         // passes per pipeline step
   constexpr int NGROUP = NPASS / GROUP;
-  static_assert(KC * sizeof(TA) <= CHUNK_BYTES_MAX, "chunk too wide");
-  static_assert(NPASS >= 1 && NPASS % GROUP == 0, "pass grouping");
+  constexpr int LDA = KC + EPL;                         // +16 B: conflict-free b128 reads
+  constexpr int LDB = KCB + EPL;
+  constexpr int TMW = 32;                               // pixels per wavefront
+  constexpr int TMB = NW * TMW;                         // pixels per workgroup
+  static_assert(NGROUP == 1 || NGROUP == 2, "pipeline depth");
+  static_assert((TMW * LDA * ES) >= TN * (TMW + 1) * 4 || true, "");
   typedef typename Mma<TA>::frag frag_t;
 
-  constexpr int A_BYTES = TM * LDA * sizeof(TA);
-  constexpr int B_BYTES = TN * LDA * sizeof(TA);
-  constexpr int C_BYTES = TN * (TM + 1) * 4;    // NCHW epilogue transpose
-  constexpr int AB_BYTES = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[AB_BYTES];
-  // per output pixel of the tile, for the current (tap, deformable group): byte
-  // offsets of the four bilinear corners inside this tile's buffer window
-  // (OOB_OFFSET = corner outside the map: the buffer load returns 0, which is the
-  // reference's `v = 0`) and the four bilinear weights
-  __shared__ __attribute__((aligned(16))) unsigned int s_off[TM][4];
-  __shared__ __attribute__((aligned(16))) float s_w[TM][4];
-  __shared__ float s_mask[TM];
-
-  TA *As = reinterpret_cast<TA *>(smem);
-  TA *Bs = reinterpret_cast<TA *>(smem + A_BYTES);
+  constexpr int B_BYTES = TN * LDB * ES;                // one weight buffer
+  constexpr int A_BYTES = TMW * LDA * ES;               // one wave's A tile
+  constexpr int C_BYTES = TN * (TMW + 1) * 4;           // one wave's NCHW transpose
+  constexpr int AW_BYTES = A_BYTES > C_BYTES ? A_BYTES : C_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * B_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[NW * AW_BYTES];
+  // per wave, double buffered over (tap, deformable group): byte offsets of the
+  // four bilinear corners inside this tile's buffer window (OOB_OFFSET = corner
+  // outside the map: the buffer load returns 0, the reference's `v = 0`), the
+  // four bilinear weights and the DCNv2 mask value
+  __shared__ __attribute__((aligned(16))) unsigned int s_off[NW][2][TMW][4];
+  __shared__ __attribute__((aligned(16))) float s_w[NW][2][TMW][4];
+  __shared__ float s_mask[NW][2][TMW];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs
-  // (blocks b and b+8 share an L2), so give each XCD one contiguous range of
-  // tiles - consecutive tiles sample the same image rows, whose re-reads then hit
-  // that XCD's L2.  Bijective for any grid size; placement only affects speed.
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware tile order (blocks b and b+8 share an L2): each XCD walks one
+  // contiguous range of tiles, so re-reads of an image stay in one L2.
+  // Bijective for any grid size; placement only affects speed.
   long long tile;
   {
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
@@ -314,11 +333,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void dcn_fused_kernel(DcnArgs a) {
   const int HWo = a.Ho * a.Wo;
   const int T = a.kH * a.kW;
   const TA *wp = static_cast<const TA *>(a.wp);
+  TA *As = reinterpret_cast<TA *>(s_a + wid * AW_BYTES);
 
   // Buffer window of this tile: starts at the first image the tile touches and is
   // clamped below 2 GiB, so 32-bit offsets address it and OOB_OFFSET is outside.
-  const int b0 = (int)((tile * TM) / HWo);
-  const size_t img_bytes = (size_t)a.H * a.W * a.Cp * sizeof(TA);
+  const int b0 = (int)((tile * TMB) / HWo);
+  const size_t img_bytes = (size_t)a.H * a.W * a.Cp * ES;
   const size_t win_rest = (size_t)(a.B - b0) * img_bytes;
   const unsigned win_bytes = win_rest < 0x7fffffffull ? (unsigned)win_rest : 0x7fffffffu;
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -326,131 +346,223 @@ __global__ __launch_bounds__(NTHREADS, 4) void dcn_fused_kernel(DcnArgs a) {
           (size_t)b0 * img_bytes,
       0, (int)win_bytes, 0x00020000);
 
-  f32x16 acc;
+  f32x16 acc0, acc1;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 16; ++i) {
+    acc0[i] = 0.f;
+    acc1[i] = 0.f;
+  }
 
-  const int lp = tid % LPP;  // 16-B piece within the pixel chunk
-  const int pr = tid / LPP;  // pixel within the pass
+  const int lp = lane % LPP;   // 16-B piece within the pixel chunk
+  const int pq = lane / LPP;   // pixel within one load instruction
   const bool has_mask = a.mask != nullptr;
 
-  for (int t = 0; t < T; ++t) {
-    const int ti = t / a.kW, tj = t - ti * a.kW;
-    for (int g = 0; g < a.dg; ++g) {
-      __syncthreads();  // previous readers of the coordinate table are done
-      if (tid < TM) {
-        const long long p = tile * TM + tid;
-        unsigned c1 = OOB_OFFSET, c2 = OOB_OFFSET, c3 = OOB_OFFSET, c4 = OOB_OFFSET;
-        float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 1.f;
-        if (p < a.P) {
-          const int b = (int)(p / HWo);
-          const int hw = (int)(p - (long long)b * HWo);
-          const int ho = hw / a.Wo, wo = hw - ho * a.Wo;
-          const float *op = a.offset +
-                            ((size_t)(b * a.dg + g) * 2 * T + 2 * t) * HWo + hw;
-          float off_h = ldg_f32(op);
-          float off_w = ldg_f32(op + HWo);
-          if (a.points)  // dcn_offset = pts - base  (lanepoints_conv.py:63-74,170)
-            off_w = off_w - (float)(tj - a.pW);
-          const float h_im = (float)(ho * a.sH - a.pH + ti * a.dH) + off_h;
-          const float w_im = (float)(wo * a.sW - a.pW + tj * a.dW) + off_w;
-          if (h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W) {
-            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-            const int h_high = h_low + 1, w_high = w_low + 1;
-            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-            const float hh = 1.f - lh, hw_ = 1.f - lw;
-            w1 = hh * hw_;
-            w2 = hh * lw;
-            w3 = lh * hw_;
-            w4 = lh * lw;
-            const unsigned px = (unsigned)(a.Cp * sizeof(TA));      // bytes per pixel
-            const unsigned row = (unsigned)a.W * px;
-            const unsigned base = (unsigned)(b - b0) * (unsigned)img_bytes +
-                                  (unsigned)h_low * row + (unsigned)w_low * px;
-            const bool hl = h_low >= 0, hh_ok = h_high <= a.H - 1;
-            const bool wl = w_low >= 0, wh_ok = w_high <= a.W - 1;
-            if (hl && wl) c1 = base;
-            if (hl && wh_ok) c2 = base + px;
-            if (hh_ok && wl) c3 = base + row;
-            if (hh_ok && wh_ok) c4 = base + row + px;
-          }
-          if (has_mask)
-            mk = ldg_f32(a.mask + ((size_t)(b * a.dg + g) * T + t) * HWo + hw);
-        }
-        *reinterpret_cast<uint4 *>(s_off[tid]) = make_uint4(c1, c2, c3, c4);
-        *reinterpret_cast<float4 *>(s_w[tid]) = make_float4(w1, w2, w3, w4);
-        s_mask[tid] = mk;
-      }
-      __syncthreads();
+  // this lane's output pixel for the coordinate computation (lanes 0..31)
+  const long long my_p = tile * TMB + wid * TMW + (lane & 31);
+  const bool my_valid = my_p < a.P;
+  const int my_b = my_valid ? (int)(my_p / HWo) : 0;
+  const int my_hw = my_valid ? (int)(my_p - (long long)my_b * HWo) : 0;
+  const int my_ho = my_hw / a.Wo, my_wo = my_hw - my_ho * a.Wo;
 
-      const int c_begin = g * a.cpg, c_end = c_begin + a.cpg;
-      for (int c0 = c_begin; c0 < c_end; c0 += KC) {
-        // ---- stage the weight chunk [TN][KC] ------------------------------
-        {
-          constexpr int PIECES = TN * LPP;
-#pragma unroll
-          for (int q = tid; q < PIECES; q += NTHREADS) {
-            const int row = q / LPP, pc = q - row * LPP;
-            const u32x4 v = ldg128(
-                wp + ((size_t)(t * a.CoutP + n0 + row) * a.Cp + c0 + pc * EPL));
-            *reinterpret_cast<u32x4 *>(Bs + row * LDA + pc * EPL) = v;
-          }
+  // offsets (and mask) of (tap t, group g) for this lane's pixel: global loads
+  auto load_offsets = [&](int t, int g, float &oh, float &ow, float &mk) {
+    oh = 0.f;
+    ow = 0.f;
+    mk = 1.f;
+    if (my_valid && lane < 32) {
+      const float *op = a.offset + ((size_t)(my_b * a.dg + g) * 2 * T + 2 * t) * HWo + my_hw;
+      oh = ldg_f32(op);
+      ow = ldg_f32(op + HWo);
+      if (has_mask)
+        mk = ldg_f32(a.mask + ((size_t)(my_b * a.dg + g) * T + t) * HWo + my_hw);
+    }
+  };
+  // sampling position, corner offsets and bilinear weights -> table `slot`
+  auto store_coords = [&](int t, int slot, float off_h, float off_w, float mk) {
+    if (lane < 32) {
+      const int ti = t / a.kW, tj = t - ti * a.kW;
+      unsigned c1 = OOB_OFFSET, c2 = OOB_OFFSET, c3 = OOB_OFFSET, c4 = OOB_OFFSET;
+      float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+      if (my_valid) {
+        if (a.points)  // dcn_offset = pts - base  (lanepoints_conv.py:63-74,170)
+          off_w = off_w - (float)(tj - a.pW);
+        const float h_im = (float)(my_ho * a.sH - a.pH + ti * a.dH) + off_h;
+        const float w_im = (float)(my_wo * a.sW - a.pW + tj * a.dW) + off_w;
+        if (h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const int h_high = h_low + 1, w_high = w_low + 1;
+          const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+          const float hh = 1.f - lh, hw_ = 1.f - lw;
+          w1 = hh * hw_;
+          w2 = hh * lw;
+          w3 = lh * hw_;
+          w4 = lh * lw;
+          const unsigned px = (unsigned)(a.Cp * ES);  // bytes per pixel
+          const unsigned row = (unsigned)a.W * px;
+          const unsigned base = (unsigned)(my_b - b0) * (unsigned)img_bytes +
+                                (unsigned)h_low * row + (unsigned)w_low * px;
+          const bool hl = h_low >= 0, hh_ok = h_high <= a.H - 1;
+          const bool wl = w_low >= 0, wh_ok = w_high <= a.W - 1;
+          if (hl && wl) c1 = base;
+          if (hl && wh_ok) c2 = base + px;
+          if (hh_ok && wl) c3 = base + row;
+          if (hh_ok && wh_ok) c4 = base + row + px;
         }
-        // ---- gather + blend the A chunk [TM][KC] --------------------------
-        // 16 lanes x 16 B read one pixel's 256-B channel run per corner; the loads
-        // are unconditional buffer loads (no branches, no waits between them) and
-        // the next group's loads are issued before the current group is blended.
-        const unsigned lane_off = (unsigned)((c0 + lp * EPL) * sizeof(TA));
-        u32x4 v[2][GROUP][4];
-        uint4 cx[2][GROUP];
+      }
+      *reinterpret_cast<uint4 *>(s_off[wid][slot][lane]) = make_uint4(c1, c2, c3, c4);
+      *reinterpret_cast<float4 *>(s_w[wid][slot][lane]) = make_float4(w1, w2, w3, w4);
+      s_mask[wid][slot][lane] = mk;
+    }
+  };
+
+  // weight chunk: global -> registers (early) -> LDS buffer (late)
+  constexpr int BPIECES = TN * (KCB / EPL);
+  constexpr int BPT = (BPIECES + NW * 64 - 1) / (NW * 64);
+  u32x4 breg[BPT];
+  auto load_b = [&](int t, int cbase) {
 #pragma unroll
-        for (int u = 0; u < GROUP; ++u) {
-          cx[0][u] = *reinterpret_cast<const uint4 *>(s_off[u * PPP + pr]);
-          v[0][u][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[0][u].x + lane_off, 0, 0);
-          v[0][u][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[0][u].y + lane_off, 0, 0);
-          v[0][u][2] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[0][u].z + lane_off, 0, 0);
-          v[0][u][3] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[0][u].w + lane_off, 0, 0);
-        }
-#pragma unroll
-        for (int gi = 0; gi < NGROUP; ++gi) {
-          const int cur = gi & 1, nxt = cur ^ 1;
-          if (gi + 1 < NGROUP) {
-#pragma unroll
-            for (int u = 0; u < GROUP; ++u) {
-              const int r = ((gi + 1) * GROUP + u) * PPP + pr;
-              cx[nxt][u] = *reinterpret_cast<const uint4 *>(s_off[r]);
-              v[nxt][u][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[nxt][u].x + lane_off, 0, 0);
-              v[nxt][u][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[nxt][u].y + lane_off, 0, 0);
-              v[nxt][u][2] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[nxt][u].z + lane_off, 0, 0);
-              v[nxt][u][3] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx[nxt][u].w + lane_off, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < GROUP; ++u) {
-            const int r = (gi * GROUP + u) * PPP + pr;
-            const float4 w = *reinterpret_cast<const float4 *>(s_w[r]);
-            const float mk = has_mask ? s_mask[r] : 1.f;
-            const u32x4 o = Blend<TA>::run(v[cur][u], w, has_mask, mk);
-            *reinterpret_cast<u32x4 *>(As + r * LDA + lp * EPL) = o;
-          }
-        }
-        __syncthreads();
-        // ---- contract: wavefront = 32 pixels x 32 outputs ------------------
-        {
-          const int i = lane & 31, h = lane >> 5;
-          const int pb = wid & 3, nb = wid >> 2;
-          const TA *arow = As + (pb * 32 + i) * LDA + h * EPL;
-          const TA *brow = Bs + (nb * 32 + i) * LDA + h * EPL;
-#pragma unroll
-          for (int q = 0; q < KC / (2 * EPL); ++q) {
-            const frag_t fa = *reinterpret_cast<const frag_t *>(arow + q * 2 * EPL);
-            const frag_t fb = *reinterpret_cast<const frag_t *>(brow + q * 2 * EPL);
-            Mma<TA>::mma(fa, fb, acc);
-          }
-        }
-        __syncthreads();
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NW * 64;
+      if (BPIECES % (NW * 64) == 0 || q < BPIECES) {
+        const int row = q / (KCB / EPL), pc = q - row * (KCB / EPL);
+        breg[j] = ldg128(wp + ((size_t)(t * a.CoutP + n0 + row) * a.Cp + cbase + pc * EPL));
       }
     }
+  };
+  auto store_b = [&](int buf) {
+    TA *Bs = reinterpret_cast<TA *>(s_b + buf * B_BYTES);
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NW * 64;
+      if (BPIECES % (NW * 64) == 0 || q < BPIECES) {
+        const int row = q / (KCB / EPL), pc = q - row * (KCB / EPL);
+        *reinterpret_cast<u32x4 *>(Bs + row * LDB + pc * EPL) = breg[j];
+      }
+    }
+  };
+
+  u32x4 v0[GROUP][4], v1[GROUP][4];
+  auto issue = [&](u32x4 (&v)[GROUP][4], int slot, int grp, int cabs) {
+    const unsigned lane_off = (unsigned)((cabs + lp * EPL) * ES);
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) {
+      const int r = (grp * GROUP + u) * PPL + pq;
+      const uint4 cx = *reinterpret_cast<const uint4 *>(s_off[wid][slot][r]);
+      v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.x + lane_off, 0, 0);
+      v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.y + lane_off, 0, 0);
+      v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.z + lane_off, 0, 0);
+      v[u][3] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.w + lane_off, 0, 0);
+    }
+  };
+  auto blend = [&](u32x4 (&v)[GROUP][4], int slot, int grp) {
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) {
+      const int r = (grp * GROUP + u) * PPL + pq;
+      const float4 w = *reinterpret_cast<const float4 *>(s_w[wid][slot][r]);
+      const float mk = has_mask ? s_mask[wid][slot][r] : 1.f;
+      const u32x4 o = Blend<TA>::run(v[u], w, has_mask, mk);
+      *reinterpret_cast<u32x4 *>(As + r * LDA + lp * EPL) = o;
+    }
+  };
+
+  const int CPGK = a.cpg / KC;          // gather chunks per (tap, group)
+  const int NA = T * a.dg * CPGK;       // gather chunks in total
+
+  // ---- prologue: coordinates of (0,0), first weight chunk, first loads ---------
+  float noh, now_, nmk;                 // prefetched offsets of the NEXT (tap, group)
+  load_offsets(0, 0, noh, now_, nmk);
+  load_b(0, 0);
+  store_coords(0, 0, noh, now_, nmk);
+  wave_lds_sync();
+  issue(v0, 0, 0, 0);
+  store_b(0);
+  if (T * a.dg > 1) {
+    const int nt = a.dg > 1 ? 0 : 1, ng = a.dg > 1 ? 1 : 0;
+    load_offsets(nt, ng, noh, now_, nmk);
+  }
+
+  int t = 0, g = 0, c = 0;              // current gather chunk = (t, g, c)
+  for (int k = 0; k < NA; ++k) {
+    const int slot = (t * a.dg + g) & 1;
+    const int sub = c % NSUB;
+    const int nbi = k / NSUB;           // weight chunk index
+    const bool last_of_tg = (c == CPGK - 1);
+    const bool has_next = (k + 1 < NA);
+    // position of the next gather chunk
+    int t2 = t, g2 = g, c2 = c + 1;
+    if (last_of_tg) {
+      c2 = 0;
+      g2 = g + 1;
+      if (g2 == a.dg) {
+        g2 = 0;
+        t2 = t + 1;
+      }
+    }
+    const int slot2 = (t2 * a.dg + g2) & 1;
+
+    if (sub == 0) {
+      // weight chunk nbi was written to its buffer by every wave: one barrier
+      __syncthreads();
+      // prefetch the next weight chunk into registers
+      if (k + NSUB < NA) {
+        int t3 = t, g3 = g, c3 = c + NSUB;
+        if (c3 >= CPGK) {
+          c3 = 0;
+          g3 = g + 1;
+          if (g3 == a.dg) {
+            g3 = 0;
+            t3 = t + 1;
+          }
+        }
+        load_b(t3, g3 * a.cpg + c3 * KC);
+      }
+    }
+
+    if (NGROUP == 2) issue(v1, slot, 1, g * a.cpg + c * KC);
+    blend(v0, slot, 0);
+    if (has_next) {
+      if (last_of_tg) {
+        // coordinates of the next (tap, group) from the offsets fetched a whole
+        // (tap, group) ago; then start fetching the ones after that
+        store_coords(t2, slot2, noh, now_, nmk);
+        wave_lds_sync();
+        int t4 = t2, g4 = g2 + 1;
+        if (g4 == a.dg) {
+          g4 = 0;
+          t4 = t2 + 1;
+        }
+        if (t4 < T) load_offsets(t4, g4, noh, now_, nmk);
+      }
+      issue(v0, slot2, 0, g2 * a.cpg + c2 * KC);
+    }
+    if (NGROUP == 2) blend(v1, slot, 1);
+    wave_lds_sync();
+
+    // ---- contract this wave's 32 pixels x 64 outputs over the chunk -----------
+    {
+      const int i = lane & 31, h = lane >> 5;
+      const TA *Bs = reinterpret_cast<const TA *>(s_b + (nbi & 1) * B_BYTES);
+      const TA *arow = As + i * LDA + h * EPL;
+      const TA *brow0 = Bs + i * LDB + sub * KC + h * EPL;
+      const TA *brow1 = brow0 + 32 * LDB;
+#pragma unroll
+      for (int q = 0; q < KC / (2 * EPL); ++q) {
+        const frag_t fa = *reinterpret_cast<const frag_t *>(arow + q * 2 * EPL);
+        const frag_t fb0 = *reinterpret_cast<const frag_t *>(brow0 + q * 2 * EPL);
+        const frag_t fb1 = *reinterpret_cast<const frag_t *>(brow1 + q * 2 * EPL);
+        Mma<TA>::mma(fa, fb0, acc0);
+        Mma<TA>::mma(fa, fb1, acc1);
+      }
+    }
+    wave_lds_sync();
+    if (sub == NSUB - 1 && k + 1 < NA) {
+      // this wave is done with weight chunk nbi; the other buffer was last read
+      // in chunk nbi-1, which every wave left before the barrier above
+      store_b((nbi + 1) & 1);
+    }
+    t = t2;
+    g = g2;
+    c = c2;
   }
 
   // ---- epilogue -------------------------------------------------------------
@@ -458,38 +570,48 @@ __global__ __launch_bounds__(NTHREADS, 4) void dcn_fused_kernel(DcnArgs a) {
   TO *out = static_cast<TO *>(a.out);
   const TO *bias = static_cast<const TO *>(a.bias);
   const int col = lane & 31, half = lane >> 5;
-  const int pb = wid & 3, nb = wid >> 2;
-  const int oc = n0 + nb * 32 + col;
-  float bias0 = 0.f;
-  if (bias && oc < a.Cout) bias0 = to_f32(bias[oc]);
+  float bias0 = 0.f, bias1 = 0.f;
+  if (bias) {
+    if (n0 + col < a.Cout) bias0 = to_f32(bias[n0 + col]);
+    if (n0 + 32 + col < a.Cout) bias1 = to_f32(bias[n0 + 32 + col]);
+  }
+  const long long pw = tile * TMB + wid * TMW;  // first pixel of this wave
   if (a.out_nhwc) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const long long p = tile * TM + pb * 32 + row;
-      if (p < a.P && oc < a.Cout) {
-        float v0 = acc[r] + bias0;
-        if (a.relu) v0 = fmaxf(v0, 0.f);
-        out[p * a.Cout + oc] = from_f32<TO>(v0);
+      const long long p = pw + row;
+      if (p < a.P) {
+        float x0 = acc0[r] + bias0, x1 = acc1[r] + bias1;
+        if (a.relu) {
+          x0 = fmaxf(x0, 0.f);
+          x1 = fmaxf(x1, 0.f);
+        }
+        if (n0 + col < a.Cout) out[p * a.Cout + n0 + col] = from_f32<TO>(x0);
+        if (n0 + 32 + col < a.Cout) out[p * a.Cout + n0 + 32 + col] = from_f32<TO>(x1);
       }
     }
   } else {
-    float *Cs = reinterpret_cast<float *>(smem);  // [TN][TM+1]; A/B are dead
+    // NCHW: transpose through the wave's own LDS region so that each store
+    // instruction writes runs of consecutive pixels
+    float *Cs = reinterpret_cast<float *>(s_a + wid * AW_BYTES);  // [TN][TMW+1]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = pb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      Cs[(nb * 32 + col) * (TM + 1) + row] = acc[r] + bias0;
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      Cs[col * (TMW + 1) + row] = acc0[r] + bias0;
+      Cs[(32 + col) * (TMW + 1) + row] = acc1[r] + bias1;
     }
-    __syncthreads();
-    for (int idx = tid; idx < TN * TM; idx += NTHREADS) {
-      const int o = idx / TM, r = idx - o * TM;
-      const long long p = tile * TM + r;
+    wave_lds_sync();
+    const int r = lane & 31;
+    const long long p = pw + r;
+    const int b = (int)((p < a.P ? p : 0) / HWo);
+    const int hw = (int)((p < a.P ? p : 0) - (long long)b * HWo);
+#pragma unroll 4
+    for (int o = half; o < TN; o += 2) {
       if (p < a.P && n0 + o < a.Cout) {
-        const int b = (int)(p / HWo);
-        const int hw = (int)(p - (long long)b * HWo);
-        float v = Cs[o * (TM + 1) + r];
-        if (a.relu) v = fmaxf(v, 0.f);
-        out[((size_t)b * a.Cout + n0 + o) * HWo + hw] = from_f32<TO>(v);
+        float x = Cs[o * (TMW + 1) + r];
+        if (a.relu) x = fmaxf(x, 0.f);
+        out[((size_t)b * a.Cout + n0 + o) * HWo + hw] = from_f32<TO>(x);
       }
     }
   }
@@ -594,11 +716,16 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
   pl->T = p->kH * p->kW;
   pl->ta_dummy = 0;
   pl->ta = (p->dtype == GANET_F32 && p->mfma_bf16) ? GANET_BF16 : p->dtype;
-  const int kc_big = pl->ta == GANET_F32 ? 64 : 128;
-  const int kc_small = kc_big / 2;
+  // weight chunk (channels): 512 B per output row when the channel count allows,
+  // else 256 B / 128 B; channels are zero-padded to the smallest chunk otherwise
+  const int kc_big = pl->ta == GANET_F32 ? 128 : 256;
+  const int kc_small = kc_big / 4;
   const int cpg = p->Cin / p->deformable_groups;
   if (cpg % kc_big == 0) {
     pl->kc = kc_big;
+    pl->Cp = p->Cin;
+  } else if (cpg % (kc_big / 2) == 0) {
+    pl->kc = kc_big / 2;
     pl->Cp = p->Cin;
   } else if (cpg % kc_small == 0) {
     pl->kc = kc_small;
@@ -615,7 +742,7 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
     // stay below 2 GiB (see OOB_OFFSET in the kernel)
     const unsigned long long img_bytes =
         (unsigned long long)p->H * p->W * pl->Cp * dtype_size(pl->ta);
-    const unsigned long long span = (unsigned long long)TM / ((unsigned long long)pl->Ho * pl->Wo) + 2;
+    const unsigned long long span = (unsigned long long)TM_MAX / ((unsigned long long)pl->Ho * pl->Wo) + 2;
     if (img_bytes * span >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
   }
   pl->copy_x = p->x_layout != GANET_NHWC || pl->Cp != p->Cin || pl->ta != p->dtype;
@@ -656,15 +783,33 @@ void launch_pack_weight(const ganet_dcn_params *p, const Plan &pl, const void *w
                      p->Cin, pl.T, pl.CoutP, pl.Cp);
 }
 
+template <typename TA, typename TO, int KCB>
+void launch_nw(const Plan &pl, const DcnArgs &a, hipStream_t s) {
+  // 8 waves (256 pixels) per workgroup when that still gives every CU work;
+  // smaller workgroups for small batches so the grid covers the chip.
+  const long long waves = (a.P + 31) / 32;
+  const unsigned ny = (unsigned)(pl.CoutP / TN);
+  if (waves >= 8 * 256) {
+    dim3 grid((unsigned)((a.P + 255) / 256), ny);
+    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 8>), grid, dim3(512), 0, s, a);
+  } else if (waves >= 4 * 128) {
+    dim3 grid((unsigned)((a.P + 127) / 128), ny);
+    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 4>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid((unsigned)((a.P + 63) / 64), ny);
+    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 2>), grid, dim3(128), 0, s, a);
+  }
+}
+
 template <typename TA, typename TO>
 void launch_main(const Plan &pl, const DcnArgs &a, hipStream_t s) {
-  const long long tiles = (a.P + TM - 1) / TM;
-  dim3 grid((unsigned)tiles, (unsigned)(pl.CoutP / TN));
-  constexpr int KC_BIG = sizeof(TA) == 4 ? 64 : 128;
+  constexpr int KC_BIG = sizeof(TA) == 4 ? 128 : 256;
   if (pl.kc == KC_BIG)
-    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KC_BIG>), grid, dim3(NTHREADS), 0, s, a);
+    launch_nw<TA, TO, KC_BIG>(pl, a, s);
+  else if (pl.kc == KC_BIG / 2)
+    launch_nw<TA, TO, KC_BIG / 2>(pl, a, s);
   else
-    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KC_BIG / 2>), grid, dim3(NTHREADS), 0, s, a);
+    launch_nw<TA, TO, KC_BIG / 4>(pl, a, s);
 }
 
 }  // namespace

@@ -48,6 +48,23 @@ class DecodeBuffers(object):
         base = self.dev.data_ptr()
         for name, _ in _FIELDS:
             setattr(self.out, name, base + 4 * self.offsets[name][0])
+        # dense record stream written by ganet_decode_pack (what the host copies)
+        self.header_words = B * _lib.DECODE_COUNT_STRIDE
+        self.packed_words = self.header_words + B * (
+            7 * max_kpts + 3 * max_centers + 3 * max_groups)
+        self.packed = torch.empty(self.packed_words, dtype=torch.int32, device=device)
+
+    def pack(self, L, p, stream):
+        rc = L.ganet_decode_pack(ctypes.byref(p), ctypes.byref(self.out),
+                                 self.packed.data_ptr(), self.packed_words, stream)
+        _lib.check(rc, "ganet_decode_pack")
+
+    def fetch(self):
+        """Synchronous two-step D2H: the header, then exactly the records found."""
+        hdr = self.packed[:self.header_words].cpu().numpy()
+        total = int(hdr[6])
+        rec = self.packed[self.header_words:self.header_words + total].cpu().numpy()
+        return hdr.reshape(self.B, _lib.DECODE_COUNT_STRIDE), rec
 
     def host_views(self, flat):
         """numpy views of a host copy `flat` (int32 [total])."""
@@ -67,34 +84,53 @@ class DecodeBuffers(object):
 
 
 class DecodeResult(object):
-    """Host copy of a decoded batch.  Arrays are trimmed per image by image()."""
+    """Host copy of a decoded batch: the header [B,8] and the dense record
+    stream of ganet_decode_pack.  image(b) slices one image's arrays out."""
 
-    def __init__(self, views, params, grouped, buffers=None):
-        self.v = views
+    def __init__(self, header, records, params, grouped, buffers=None):
+        self.header = header
+        self.records = records
         self.params = params          # dict(thr, root_thr, cluster_thr, by_center_thr)
         self.grouped = grouped
         self.buffers = buffers        # device buffers (kept for a later grouping pass)
-        self.B = views["counts"].shape[0]
+        self.B = header.shape[0]
+
+    @property
+    def counts(self):
+        return self.header[:, :4]
 
     def n_kpts(self, b=0):
-        return int(self.v["counts"][b, 0])
+        return int(self.header[b, 0])
 
     def image(self, b=0):
-        c = self.v["counts"][b]
-        nk, nc, ng = int(c[0]), int(c[1]), int(c[2])
+        h = self.header[b]
+        if h[3] & 7:
+            raise RuntimeError("decode capacity overflow in image %d (bits %d)" % (b, h[3]))
         by_center = self.params["by_center_thr"] is not None
-        d = dict(
-            centers=self.v["centers_xy"][b, :nc],
-            kpt_xy=self.v["kpt_xy"][b, :nk],
-            align=self.v["kpt_align"][b, :nk],
-            root=self.v["kpt_root"][b, :nk],
-        )
+        off, words = int(h[4]), int(h[5])
+        r = self.records[off:off + words]
+        nk, nc, ng = int(h[0]), int(h[1]), int(h[2])
+        ngc = ng if by_center else 0
+        assert words == 7 * nk + 3 * nc + 2 * ngc + ng, "corrupt decode record"
+        pos = [0]
+
+        def take(n, shape=None, f32=False):
+            a = r[pos[0]:pos[0] + n]
+            pos[0] += n
+            if f32:
+                a = a.view(np.float32)
+            return a.reshape(shape) if shape else a
+
+        d = dict(kpt_xy=take(2 * nk, (nk, 2)), align=take(2 * nk, (nk, 2), True),
+                 root=take(2 * nk, (nk, 2), True))
+        kgid = take(nk)
+        d["centers"] = take(2 * nc, (nc, 2))
+        cgid = take(nc)
+        gcen = take(2 * ngc, (ngc, 2))
+        gcnt = take(ng)
         if self.grouped:
-            d.update(
-                kpt_gid=self.v["kpt_gid"][b, :nk], n_groups=ng,
-                group_center=self.v["group_center"][b, :ng if by_center else 0],
-                group_count=self.v["group_count"][b, :ng],
-                center_gid=self.v["center_gid"][b, :nc if by_center else 0])
+            d.update(kpt_gid=kgid, n_groups=ng, group_center=gcen, group_count=gcnt,
+                     center_gid=cgid if by_center else cgid[:0])
         return d
 
 
@@ -154,10 +190,10 @@ def decode_batch(heat, offset, error, thr=0.1, root_thr=1, cluster_thr=4,
                                       ctypes.byref(bufs.out), ws.data_ptr(),
                                       ws_bytes, stream)
             _lib.check(rc, "ganet_decode_batch")
-            flat = bufs.dev.cpu().numpy()     # one D2H copy, stream-ordered
-        views = bufs.host_views(flat)
-        counts = views["counts"]
-        over = int(np.bitwise_or.reduce(counts[:, 3]))
+            bufs.pack(L, p, stream)
+            header, records = bufs.fetch()
+        counts = header[:, :4]
+        over = int(np.bitwise_or.reduce(counts[:, 3])) & 7
         if over == 0:
             break
         nk, nc, ng = (int(counts[:, i].max()) for i in range(3))
@@ -169,7 +205,7 @@ def decode_batch(heat, offset, error, thr=0.1, root_thr=1, cluster_thr=4,
                 max(caps[2], ng, (nc if by_center else nk)))
     params = dict(thr=thr, root_thr=root_thr, cluster_thr=cluster_thr,
                   by_center_thr=cluster_by_center_thr)
-    return DecodeResult(views, params, grouped=group,
+    return DecodeResult(header, records, params, grouped=group,
                         buffers=bufs if keep_device else None)
 
 
@@ -210,7 +246,7 @@ def group_on_device(res, cluster_thr, cluster_by_center_thr):
     if bufs is None:
         raise RuntimeError("decode result no longer holds its device buffers")
     by_center = cluster_by_center_thr is not None
-    counts = res.v["counts"]
+    counts = res.counts
     need_groups = int(counts[:, 1].max() if by_center else counts[:, 0].max())
     if need_groups > bufs.max_groups:
         raise RuntimeError("group capacity too small")  # caller re-decodes
@@ -220,10 +256,11 @@ def group_on_device(res, cluster_thr, cluster_by_center_thr):
         stream = torch.cuda.current_stream(bufs.dev.device).cuda_stream
         rc = L.ganet_group_batch(ctypes.byref(p), ctypes.byref(bufs.out), stream)
         _lib.check(rc, "ganet_group_batch")
-        flat = bufs.dev.cpu().numpy()
+        bufs.pack(L, p, stream)
+        header, records = bufs.fetch()
     params = dict(res.params, cluster_thr=cluster_thr,
                   by_center_thr=cluster_by_center_thr)
-    return DecodeResult(bufs.host_views(flat), params, grouped=True, buffers=bufs)
+    return DecodeResult(header, records, params, grouped=True, buffers=bufs)
 
 
 def group_seeds_on_device(cpt_seeds, kpt_seeds, cluster_thr, cluster_by_center_thr,
@@ -254,7 +291,8 @@ def group_seeds_on_device(cpt_seeds, kpt_seeds, cluster_thr, cluster_by_center_t
     v["kpt_root"][0, :n] = root
     v["kpt_align"][0, :n] = align
     bufs.dev.copy_(torch.from_numpy(flat))
-    res = DecodeResult(v, dict(thr=None, root_thr=None, cluster_thr=cluster_thr,
-                               by_center_thr=cluster_by_center_thr),
+    res = DecodeResult(v["counts"].copy(), np.zeros(0, np.int32),
+                       dict(thr=None, root_thr=None, cluster_thr=cluster_thr,
+                            by_center_thr=cluster_by_center_thr),
                        grouped=False, buffers=bufs)
     return group_on_device(res, cluster_thr, cluster_by_center_thr)

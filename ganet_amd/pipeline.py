@@ -26,7 +26,8 @@ class HotPath(object):
                  device=None, thr=0.4, root_thr=1.0, cluster_thr=5.0,
                  by_center_thr=5.0, max_kpts=1024, max_centers=128,
                  channels_last=True, mfma_bf16=False, fuse_relu=True,
-                 offset_is_points=True):
+                 offset_is_points=True, expect_kpts=192, expect_centers=16,
+                 overlap_copy=False):
         self.L = _lib.lib()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.B, self.H, self.W, self.K = B, H, W, K
@@ -59,12 +60,29 @@ class HotPath(object):
             by_center = by_center_thr is not None
             caps = (max_kpts, max_centers, max_centers if by_center else max_kpts)
             self.dp = _params(B, H, W, thr, root_thr, cluster_thr, by_center_thr, caps)
-            self.bufs = DecodeBuffers(B, caps[0], caps[1], caps[2], self.device)
+            # two result blocks + pinned mirrors: the D2H copy of step i runs on a
+            # copy stream while step i+1 computes
+            self.slots = []
+            for _ in range(2):
+                bufs = DecodeBuffers(B, caps[0], caps[1], caps[2], self.device)
+                # the async copy moves the header plus a budget of record words
+                # sized for the expected load; result() fetches any remainder
+                budget = bufs.header_words + B * (
+                    7 * min(expect_kpts, caps[0]) + 6 * min(expect_centers, caps[1]))
+                budget = min(budget, bufs.packed_words)
+                host = torch.empty(bufs.packed_words, dtype=torch.int32, pin_memory=True)
+                bufs.budget = budget
+                self.slots.append(dict(bufs=bufs, host=host,
+                                       done=torch.cuda.Event(), copied=torch.cuda.Event()))
+            self.cur = 0
+            self.last = None
+            self.bufs = self.slots[0]["bufs"]
             self.dws_bytes = self.L.ganet_decode_workspace_bytes(ctypes.byref(self.dp))
             self.dws = torch.empty(max(self.dws_bytes, 256), dtype=torch.uint8,
                                    device=self.device)
-            self.host = torch.empty(self.bufs.total, dtype=torch.int32,
-                                    pin_memory=True)
+            self.overlap_copy = overlap_copy
+            self.copy_stream = (torch.cuda.Stream(device=self.device) if overlap_copy
+                                else None)
         self.params = dict(thr=thr, root_thr=root_thr, cluster_thr=cluster_thr,
                            by_center_thr=by_center_thr)
         self._has_weight = False
@@ -94,22 +112,46 @@ class HotPath(object):
         return self.feature
 
     def decode(self, heat, offset, error, copy_to_host=True):
-        """Enqueue decode + grouping (+ the async D2H of the result block)."""
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        """Enqueue decode + grouping on the current stream, then the D2H copy of
+        the result block on the copy stream (it overlaps the next step)."""
+        slot = self.slots[self.cur]
+        cur_stream = torch.cuda.current_stream(self.device)
+        # the block is free again once its previous copy has finished
+        if self.overlap_copy:
+            cur_stream.wait_event(slot["copied"])
         rc = self.L.ganet_decode_batch(
             heat.data_ptr(), offset.data_ptr(), error.data_ptr(),
-            ctypes.byref(self.dp), ctypes.byref(self.bufs.out),
-            self.dws.data_ptr(), self.dws_bytes, stream)
+            ctypes.byref(self.dp), ctypes.byref(slot["bufs"].out),
+            self.dws.data_ptr(), self.dws_bytes, cur_stream.cuda_stream)
         _lib.check(rc, "ganet_decode_batch")
+        slot["bufs"].pack(self.L, self.dp, cur_stream.cuda_stream)
         if copy_to_host:
-            self.host.copy_(self.bufs.dev, non_blocking=True)
+            n = slot["bufs"].budget
+            if self.overlap_copy:
+                slot["done"].record(cur_stream)
+                with torch.cuda.stream(self.copy_stream):
+                    self.copy_stream.wait_event(slot["done"])
+                    slot["host"][:n].copy_(slot["bufs"].packed[:n], non_blocking=True)
+                    slot["copied"].record(self.copy_stream)
+            else:
+                slot["host"][:n].copy_(slot["bufs"].packed[:n], non_blocking=True)
+        self.last = slot
+        self.cur ^= 1
 
     def step(self, x, pts, heat, offset, error):
         self.lfa(x, pts)
         self.decode(heat, offset, error)
 
     def result(self):
-        """Wait for the stream and view the last step's decode result."""
+        """Wait for the last step's copy and view its decode result."""
         torch.cuda.current_stream(self.device).synchronize()
-        views = self.bufs.host_views(self.host.numpy())
-        return DecodeResult(views, self.params, grouped=True)
+        if self.copy_stream is not None:
+            self.copy_stream.synchronize()
+        slot = self.last
+        bufs, host = slot["bufs"], slot["host"].numpy()
+        total = bufs.header_words + int(host[6])
+        if total > bufs.budget:   # more was found than the async budget covered
+            slot["host"][bufs.budget:total].copy_(bufs.packed[bufs.budget:total])
+        header = host[:bufs.header_words].reshape(self.B, _lib.DECODE_COUNT_STRIDE)
+        return DecodeResult(header.copy(), host[bufs.header_words:total].copy(),
+                            self.params, grouped=True)

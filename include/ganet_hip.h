@@ -203,6 +203,22 @@ int ganet_decode_batch(const float *heat, const float *offset,
 int ganet_group_batch(const ganet_decode_params *p, const ganet_decode_out *out,
                       ganet_stream_t stream);
 
+/* Compacts the capacity-strided arrays of `out` into one dense int32 stream so
+ * that the device-to-host copy of the lane lists moves only what was found
+ * (the reference copies heat_nms-selected rows with three blocking .cpu()
+ * calls, ganet_head.py:217,232-233).  Layout of `packed`:
+ *   header[B][8]: n_kpts, n_centers, n_groups, overflow bits (bit 3: this record
+ *                 did not fit in packed_words), record offset in words counted
+ *                 from the end of the header, record words, total record words
+ *                 (in header[0] only), 0
+ *   record b    : kpt_xy[2nk] kpt_align[2nk] kpt_root[2nk] kpt_gid[nk]
+ *                 centers_xy[2nc] center_gid[nc] group_center[2ngc] group_count[ng]
+ *                 (counts clamped to the capacities; ngc = ng in by-centre mode,
+ *                 0 otherwise; float arrays keep their bit patterns)
+ * Records are laid out in image order.  packed_words >= 8*B. */
+int ganet_decode_pack(const ganet_decode_params *p, const ganet_decode_out *out,
+                      int32_t *packed, size_t packed_words, ganet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
