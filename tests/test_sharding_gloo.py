@@ -1,0 +1,77 @@
+"""N>1 path on CPU: world_size 2 over gloo.  The per-image work is done by the
+CPU oracle here (test stand-in for the GPU kernels); what is under test is the
+block split, the absence of any data-path collective and the host gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ganet_amd import sharding, synth
+
+
+def test_shard_ranges_partition_the_batch():
+    for n in (0, 1, 7, 128, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _lanes_of_block(lo, hi, B):
+    from oracle import cpu_oracle as O
+    cfg = synth.SHAPES["s8_tusimple"]
+    heat, off, err = synth.decode_inputs(B, cfg["H"], cfg["W"], lanes=4, seed=21)
+    out = []
+    for b in range(lo, hi):
+        c, kxy, al, rt = O.decode(heat[b], off[b], err[b], cfg["thr"], 1.0)
+        gid, means, cgid, ng = O.group_fast(c, rt, cfg["T"], cfg["T"])
+        out.append((b, gid.tobytes(), means.tobytes(), al.tobytes()))
+    return out
+
+
+def _worker(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = sharding.run_sharded(lambda lo, hi: _lanes_of_block(lo, hi, B), B)
+        if rank == 0:
+            q.put(res)
+        else:
+            assert res is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gather_equals_single_process():
+    B, world = 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = _lanes_of_block(0, B, B)
+    assert [g[0] for g in got] == list(range(B))
+    assert got == want
