@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0, help="profiling only")
+    ap.add_argument("--pts", default="synthetic", choices=["synthetic", "zero"])
     ap.add_argument("--overlap-copy", action="store_true",
                     help="copy the lane lists D2H on a second stream")
     args = ap.parse_args()
@@ -185,7 +187,10 @@ def main():
     hp = HotPath(B, H, W, Cin=Cin, Cout=64, K=K, dtype=TORCH_DTYPE[dtype], device=dev,
                  thr=cfg["thr"], root_thr=cfg["root_thr"], cluster_thr=T, by_center_thr=T,
                  max_kpts=min(H * W, 4096 if cfg["lanes"] > 4 else 1024),
-                 max_centers=256, overlap_copy=args.overlap_copy)
+                 max_centers=256, overlap_copy=args.overlap_copy,
+                 ablate=args.ablate)
+    if args.pts == "zero":
+        d["pts"].zero_()
     hp.set_weight(d["w"])
 
     def one_step(ev=None):

@@ -28,6 +28,7 @@ def _newer(a, b):
 
 def build_lib(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = ["-DGANET_ABLATE"] if os.environ.get("GANET_ABLATE") else []  # profiling build
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(ROOT, "include", "ganet_hip.h"),
                os.path.join(CSRC, "common.h")]
@@ -37,7 +38,7 @@ def build_lib(force=False, verbose=False):
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in headers):
-            cmd = [hipcc] + COMMON + PER_FILE.get(src, []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + extra + PER_FILE.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

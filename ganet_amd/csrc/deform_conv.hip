@@ -29,6 +29,8 @@
 //   epilogue: optional bias / ReLU, NHWC direct from the accumulators or NCHW
 //   through an LDS transpose so that stores stay coalesced.
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -149,6 +151,7 @@ struct DcnArgs {
   int kH, kW, sH, sW, pH, pW, dH, dW;
   int dg, cpg;          // deformable groups, channels per group (of Cp)
   int out_nhwc, relu, points;
+  int ablate;           // GANET_ABLATE builds only: bit0 skip MFMAs, bit1 skip gather loads
   long long P;          // B*Ho*Wo
 };
 
@@ -192,14 +195,15 @@ struct Mma<f16_t> {
 
 // Bilinear blend of four 16-byte pieces (one per corner) with per-pixel weights,
 // two channels per instruction (v_pk_mul/fma_f32).
-//   w1*v1 + w2*v2 + w3*v3 + w4*v4   (deform_conv_cuda_kernel.cu:111-113), * mask (:627)
+//   w1*v1 + w2*v2 + w3*v3 + w4*v4   (deform_conv_cuda_kernel.cu:111-113)
+// The DCNv2 mask (:627, `val * mask`) is folded into the four weights by the
+// caller (w_i * mask): same value up to one fp32 rounding, and branch-free.
 template <typename TA>
 struct Blend;
 
 template <>
 struct Blend<float> {
-  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w,
-                                              bool has_mask, float mk) {
+  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w) {
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -211,7 +215,6 @@ struct Blend<float> {
       r = b * w.y + r;
       r = c * w.z + r;
       r = d * w.w + r;
-      if (has_mask) r = r * mk;
       o[2 * i] = __float_as_uint(r.x);
       o[2 * i + 1] = __float_as_uint(r.y);
     }
@@ -225,8 +228,7 @@ struct Blend<bf16_t> {
     f32x2 r = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
     return r;
   }
-  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w,
-                                              bool has_mask, float mk) {
+  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w) {
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -234,7 +236,6 @@ struct Blend<bf16_t> {
       r = up(v[1][i]) * w.y + r;
       r = up(v[2][i]) * w.z + r;
       r = up(v[3][i]) * w.w + r;
-      if (has_mask) r = r * mk;
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       const bf16x2 p = {(__bf16)r.x, (__bf16)r.y};  // v_cvt_pk_bf16_f32: RNE, NaN kept
       o[i] = __builtin_bit_cast(unsigned int, p);
@@ -251,8 +252,7 @@ struct Blend<f16_t> {
     f32x2 r = {(float)h.x, (float)h.y};
     return r;
   }
-  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w,
-                                              bool has_mask, float mk) {
+  __device__ static __forceinline__ u32x4 run(const u32x4 *v, const float4 &w) {
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -260,7 +260,6 @@ struct Blend<f16_t> {
       r = up(v[1][i]) * w.y + r;
       r = up(v[2][i]) * w.z + r;
       r = up(v[3][i]) * w.w + r;
-      if (has_mask) r = r * mk;
       const f16x2 p = {(_Float16)r.x, (_Float16)r.y};
       o[i] = __builtin_bit_cast(unsigned int, p);
     }
@@ -288,34 +287,31 @@ template <typename TA, typename TO, int KCB, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
   constexpr int ES = sizeof(TA);
   constexpr int EPL = 16 / ES;                          // elements per 16-B piece
-  constexpr int KC = (KCB * ES > 256) ? 256 / ES : KCB; // gather chunk (elements)
+  constexpr int KC = (KCB * ES > 128) ? 128 / ES : KCB; // gather chunk (elements)
   constexpr int NSUB = KCB / KC;                        // gather chunks per weight chunk
   constexpr int LPP = KC / EPL;                         // lanes per pixel chunk
   constexpr int PPL = 64 / LPP;                         // pixels per load instruction
   constexpr int NPASS = 32 / PPL;                       // load passes per gather chunk
-  constexpr int GROUP = NPASS >= 4 ? 4 : NPASS;         // passes per pipeline step
-  constexpr int NGROUP = NPASS / GROUP;
+  constexpr int GROUP = NPASS;                          // one pipeline step = one chunk
   constexpr int LDA = KC + EPL;                         // +16 B: conflict-free b128 reads
   constexpr int LDB = KCB + EPL;
   constexpr int TMW = 32;                               // pixels per wavefront
   constexpr int TMB = NW * TMW;                         // pixels per workgroup
-  static_assert(NGROUP == 1 || NGROUP == 2, "pipeline depth");
-  static_assert((TMW * LDA * ES) >= TN * (TMW + 1) * 4 || true, "");
   typedef typename Mma<TA>::frag frag_t;
 
   constexpr int B_BYTES = TN * LDB * ES;                // one weight buffer
-  constexpr int A_BYTES = TMW * LDA * ES;               // one wave's A tile
-  constexpr int C_BYTES = TN * (TMW + 1) * 4;           // one wave's NCHW transpose
-  constexpr int AW_BYTES = A_BYTES > C_BYTES ? A_BYTES : C_BYTES;
+  constexpr int A_BYTES = TMW * LDA * ES;               // one wave's A tile (x2: double buffer)
+  constexpr int C_BYTES = 32 * (TMW + 1) * 4;           // NCHW transpose of one 32x32 block
+  constexpr int A0_BYTES = A_BYTES > C_BYTES ? A_BYTES : C_BYTES;  // A buffer 0 / transpose
   __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * B_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char s_a[NW * AW_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char s_a0[NW * A0_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char s_a1[NW * A_BYTES];
   // per wave, double buffered over (tap, deformable group): byte offsets of the
   // four bilinear corners inside this tile's buffer window (OOB_OFFSET = corner
-  // outside the map: the buffer load returns 0, the reference's `v = 0`), the
-  // four bilinear weights and the DCNv2 mask value
+  // outside the map: the buffer load returns 0, the reference's `v = 0`) and the
+  // four bilinear weights (times the DCNv2 mask value)
   __shared__ __attribute__((aligned(16))) unsigned int s_off[NW][2][TMW][4];
   __shared__ __attribute__((aligned(16))) float s_w[NW][2][TMW][4];
-  __shared__ float s_mask[NW][2][TMW];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -333,7 +329,8 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
   const int HWo = a.Ho * a.Wo;
   const int T = a.kH * a.kW;
   const TA *wp = static_cast<const TA *>(a.wp);
-  TA *As = reinterpret_cast<TA *>(s_a + wid * AW_BYTES);
+  TA *A0 = reinterpret_cast<TA *>(s_a0 + wid * A0_BYTES);   // chunks 0, 2, 4, ...
+  TA *A1 = reinterpret_cast<TA *>(s_a1 + wid * A_BYTES);    // chunks 1, 3, 5, ...
 
   // Buffer window of this tile: starts at the first image the tile touches and is
   // clamped below 2 GiB, so 32-bit offsets address it and OOB_OFFSET is outside.
@@ -410,8 +407,8 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
         }
       }
       *reinterpret_cast<uint4 *>(s_off[wid][slot][lane]) = make_uint4(c1, c2, c3, c4);
-      *reinterpret_cast<float4 *>(s_w[wid][slot][lane]) = make_float4(w1, w2, w3, w4);
-      s_mask[wid][slot][lane] = mk;
+      *reinterpret_cast<float4 *>(s_w[wid][slot][lane]) =
+          make_float4(w1 * mk, w2 * mk, w3 * mk, w4 * mk);
     }
   };
 
@@ -441,108 +438,109 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
     }
   };
 
-  u32x4 v0[GROUP][4], v1[GROUP][4];
-  auto issue = [&](u32x4 (&v)[GROUP][4], int slot, int grp, int cabs) {
+  u32x4 va[GROUP][4], vb[GROUP][4];
+  auto issue = [&](u32x4 (&v)[GROUP][4], int slot, int cabs) {
     const unsigned lane_off = (unsigned)((cabs + lp * EPL) * ES);
 #pragma unroll
     for (int u = 0; u < GROUP; ++u) {
-      const int r = (grp * GROUP + u) * PPL + pq;
+      const int r = u * PPL + pq;
       const uint4 cx = *reinterpret_cast<const uint4 *>(s_off[wid][slot][r]);
+#ifdef GANET_ABLATE  // profiling build only (tools/ablate.sh): skip the gather loads
+      if (a.ablate & 2) {
+        v[u][0] = v[u][1] = v[u][2] = v[u][3] = u32x4{cx.x, cx.y, cx.z, cx.w + lane_off};
+        continue;
+      }
+#endif
       v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.x + lane_off, 0, 0);
       v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.y + lane_off, 0, 0);
       v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.z + lane_off, 0, 0);
       v[u][3] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.w + lane_off, 0, 0);
     }
   };
-  auto blend = [&](u32x4 (&v)[GROUP][4], int slot, int grp) {
+  auto blend = [&](u32x4 (&v)[GROUP][4], int slot, TA *Adst) {
 #pragma unroll
     for (int u = 0; u < GROUP; ++u) {
-      const int r = (grp * GROUP + u) * PPL + pq;
+      const int r = u * PPL + pq;
       const float4 w = *reinterpret_cast<const float4 *>(s_w[wid][slot][r]);
-      const float mk = has_mask ? s_mask[wid][slot][r] : 1.f;
-      const u32x4 o = Blend<TA>::run(v[u], w, has_mask, mk);
-      *reinterpret_cast<u32x4 *>(As + r * LDA + lp * EPL) = o;
+      const u32x4 o = Blend<TA>::run(v[u], w);
+      *reinterpret_cast<u32x4 *>(Adst + r * LDA + lp * EPL) = o;
     }
   };
 
   const int CPGK = a.cpg / KC;          // gather chunks per (tap, group)
-  const int NA = T * a.dg * CPGK;       // gather chunks in total
+  const int NTG = T * a.dg;             // (tap, group) pairs
+  const int NA = NTG * CPGK;            // gather chunks in total
 
-  // ---- prologue: coordinates of (0,0), first weight chunk, first loads ---------
-  float noh, now_, nmk;                 // prefetched offsets of the NEXT (tap, group)
+  // Chunk j = (tg, c): tg = j / CPGK enumerates (tap, group) pairs tap-major.
+  // Three cursors run through the chunks: MFMA at k, blend at k+1, loads at k+2.
+  float noh, now_, nmk;                 // prefetched offsets of the next (tap, group)
+  int tg_coords = 0;                    // (tap, group) pairs whose table is written
+  // make the coordinate table of pair `tg` available (tables are double buffered)
+  auto ensure_coords = [&](int tg) {
+    if (tg == tg_coords) {
+      store_coords(tg / a.dg, tg & 1, noh, now_, nmk);
+      wave_lds_sync();
+      ++tg_coords;
+      if (tg_coords < NTG) load_offsets(tg_coords / a.dg, tg_coords % a.dg, noh, now_, nmk);
+    }
+  };
+  auto issue_chunk = [&](u32x4 (&v)[GROUP][4], int j) {
+    const int tg = j / CPGK, c = j - tg * CPGK;
+    ensure_coords(tg);
+    issue(v, tg & 1, (tg % a.dg) * a.cpg + c * KC);
+  };
+  auto wchunk_origin = [&](int nb, int &t, int &cbase) {   // weight chunk nb
+    const int j = nb * NSUB;
+    const int tg = j / CPGK, c = j - tg * CPGK;
+    t = tg / a.dg;
+    cbase = (tg % a.dg) * a.cpg + c * KC;
+  };
+
+  // ---- prologue ---------------------------------------------------------------
   load_offsets(0, 0, noh, now_, nmk);
   load_b(0, 0);
-  store_coords(0, 0, noh, now_, nmk);
-  wave_lds_sync();
-  issue(v0, 0, 0, 0);
+  issue_chunk(va, 0);
   store_b(0);
-  if (T * a.dg > 1) {
-    const int nt = a.dg > 1 ? 0 : 1, ng = a.dg > 1 ? 1 : 0;
-    load_offsets(nt, ng, noh, now_, nmk);
-  }
+  if (NA > 1) issue_chunk(vb, 1);
+  blend(va, 0, A0);
 
-  int t = 0, g = 0, c = 0;              // current gather chunk = (t, g, c)
-  for (int k = 0; k < NA; ++k) {
-    const int slot = (t * a.dg + g) & 1;
-    const int sub = c % NSUB;
+  // One step: loads of chunk k+2 go out, chunk k+1 is blended into the other A
+  // buffer, chunk k is contracted - three independent instruction streams (VMEM
+  // issue, VALU + ds_write, ds_read + MFMA) that sit in ONE basic block so the
+  // scheduler can interleave them; everything conditional (barrier, weight
+  // staging, coordinate tables) happens before or after that block.
+  auto step = [&](int k, u32x4 (&vcur)[GROUP][4], u32x4 (&vnxt)[GROUP][4],
+                  const TA *Acur, TA *Anxt, auto do_issue, auto do_blend) {
+    const int sub = k % NSUB;
     const int nbi = k / NSUB;           // weight chunk index
-    const bool last_of_tg = (c == CPGK - 1);
-    const bool has_next = (k + 1 < NA);
-    // position of the next gather chunk
-    int t2 = t, g2 = g, c2 = c + 1;
-    if (last_of_tg) {
-      c2 = 0;
-      g2 = g + 1;
-      if (g2 == a.dg) {
-        g2 = 0;
-        t2 = t + 1;
-      }
-    }
-    const int slot2 = (t2 * a.dg + g2) & 1;
-
     if (sub == 0) {
       // weight chunk nbi was written to its buffer by every wave: one barrier
       __syncthreads();
-      // prefetch the next weight chunk into registers
-      if (k + NSUB < NA) {
-        int t3 = t, g3 = g, c3 = c + NSUB;
-        if (c3 >= CPGK) {
-          c3 = 0;
-          g3 = g + 1;
-          if (g3 == a.dg) {
-            g3 = 0;
-            t3 = t + 1;
-          }
-        }
-        load_b(t3, g3 * a.cpg + c3 * KC);
+      if ((nbi + 1) * NSUB < NA) {      // prefetch the next weight chunk into registers
+        int t3, cb3;
+        wchunk_origin(nbi + 1, t3, cb3);
+        load_b(t3, cb3);
       }
+    } else {
+      wave_lds_sync();                  // A[k&1] written in the previous step
     }
-
-    if (NGROUP == 2) issue(v1, slot, 1, g * a.cpg + c * KC);
-    blend(v0, slot, 0);
-    if (has_next) {
-      if (last_of_tg) {
-        // coordinates of the next (tap, group) from the offsets fetched a whole
-        // (tap, group) ago; then start fetching the ones after that
-        store_coords(t2, slot2, noh, now_, nmk);
-        wave_lds_sync();
-        int t4 = t2, g4 = g2 + 1;
-        if (g4 == a.dg) {
-          g4 = 0;
-          t4 = t2 + 1;
-        }
-        if (t4 < T) load_offsets(t4, g4, noh, now_, nmk);
-      }
-      issue(v0, slot2, 0, g2 * a.cpg + c2 * KC);
+    int islot = 0, icabs = 0;
+    if (decltype(do_issue)::value) {
+      const int tg = (k + 2) / CPGK, c = (k + 2) - tg * CPGK;
+      ensure_coords(tg);
+      islot = tg & 1;
+      icabs = (tg % a.dg) * a.cpg + c * KC;
     }
-    if (NGROUP == 2) blend(v1, slot, 1);
-    wave_lds_sync();
-
-    // ---- contract this wave's 32 pixels x 64 outputs over the chunk -----------
+    const int bslot = ((k + 1) / CPGK) & 1;
+    // ---- hot block -----------------------------------------------------------
+    // program order: loads, MFMA operands + MFMAs, blend.  The blend's VALU work
+    // does not depend on the MFMAs and its LDS writes go to the other A buffer,
+    // so the scheduler is free to pull it up between the MFMAs.
+    if (decltype(do_issue)::value) issue(vcur, islot, icabs);
     {
       const int i = lane & 31, h = lane >> 5;
       const TA *Bs = reinterpret_cast<const TA *>(s_b + (nbi & 1) * B_BYTES);
-      const TA *arow = As + i * LDA + h * EPL;
+      const TA *arow = Acur + i * LDA + h * EPL;
       const TA *brow0 = Bs + i * LDB + sub * KC + h * EPL;
       const TA *brow1 = brow0 + 32 * LDB;
 #pragma unroll
@@ -550,20 +548,60 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
         const frag_t fa = *reinterpret_cast<const frag_t *>(arow + q * 2 * EPL);
         const frag_t fb0 = *reinterpret_cast<const frag_t *>(brow0 + q * 2 * EPL);
         const frag_t fb1 = *reinterpret_cast<const frag_t *>(brow1 + q * 2 * EPL);
+#ifdef GANET_ABLATE  // profiling build only: skip the MFMAs, keep their operands live
+        if (a.ablate & 1) {
+          asm volatile("" ::"v"(fa), "v"(fb0), "v"(fb1));
+          continue;
+        }
+#endif
         Mma<TA>::mma(fa, fb0, acc0);
         Mma<TA>::mma(fa, fb1, acc1);
       }
     }
-    wave_lds_sync();
+    if (decltype(do_blend)::value) blend(vnxt, bslot, Anxt);
+    // Interleave hint for the in-order issue: after each MFMA a few VALU (blend /
+    // address), one LDS and (every other slot) one buffer-load instruction, so the
+    // matrix pipe runs while this wave's vector and memory work issues.
+    {
+      constexpr int NMFMA = (KC / (2 * EPL)) * 2 * (ES == 4 ? 4 : 1);
+      constexpr int VPER = ES == 4 ? 2 : 10;
+#pragma unroll
+      for (int i = 0; i < NMFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);   // VALU
+        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);      // DS
+        if ((i & 1) == 0 || ES != 4)
+          __builtin_amdgcn_sched_group_barrier(0x020, ES == 4 ? 1 : 2, 0);  // VMEM read
+      }
+    }
+    // ---------------------------------------------------------------------------
     if (sub == NSUB - 1 && k + 1 < NA) {
       // this wave is done with weight chunk nbi; the other buffer was last read
       // in chunk nbi-1, which every wave left before the barrier above
       store_b((nbi + 1) & 1);
     }
-    t = t2;
-    g = g2;
-    c = c2;
+  };
+  {
+    const std::true_type yes{};
+    const std::false_type no{};
+    int k = 0;
+    for (; k + 3 < NA; k += 2) {
+      step(k, va, vb, A0, A1, yes, yes);
+      step(k + 1, vb, va, A1, A0, yes, yes);
+    }
+    const int rest = NA - k;            // 1, 2 or 3 chunks left (k is even)
+    if (rest == 3) {
+      step(k, va, vb, A0, A1, yes, yes);
+      step(k + 1, vb, va, A1, A0, no, yes);
+      step(k + 2, va, vb, A0, A1, no, no);
+    } else if (rest == 2) {
+      step(k, va, vb, A0, A1, no, yes);
+      step(k + 1, vb, va, A1, A0, no, no);
+    } else {
+      step(k, va, vb, A0, A1, no, no);
+    }
   }
+  wave_lds_sync();
 
   // ---- epilogue -------------------------------------------------------------
   // accumulator map (32x32): column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -592,27 +630,31 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
       }
     }
   } else {
-    // NCHW: transpose through the wave's own LDS region so that each store
-    // instruction writes runs of consecutive pixels
-    float *Cs = reinterpret_cast<float *>(s_a + wid * AW_BYTES);  // [TN][TMW+1]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      Cs[col * (TMW + 1) + row] = acc0[r] + bias0;
-      Cs[(32 + col) * (TMW + 1) + row] = acc1[r] + bias1;
-    }
-    wave_lds_sync();
+    // NCHW: transpose each 32x32 accumulator through the wave's own LDS region so
+    // that each store instruction writes runs of consecutive pixels
+    float *Cs = reinterpret_cast<float *>(s_a0 + wid * A0_BYTES);  // [32][TMW+1]
     const int r = lane & 31;
     const long long p = pw + r;
     const int b = (int)((p < a.P ? p : 0) / HWo);
     const int hw = (int)((p < a.P ? p : 0) - (long long)b * HWo);
-#pragma unroll 4
-    for (int o = half; o < TN; o += 2) {
-      if (p < a.P && n0 + o < a.Cout) {
-        float x = Cs[o * (TMW + 1) + r];
-        if (a.relu) x = fmaxf(x, 0.f);
-        out[((size_t)b * a.Cout + n0 + o) * HWo + hw] = from_f32<TO>(x);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        Cs[col * (TMW + 1) + row] = nb == 0 ? acc0[rr] + bias0 : acc1[rr] + bias1;
       }
+      wave_lds_sync();
+#pragma unroll 4
+      for (int o = half; o < 32; o += 2) {
+        const int oc = n0 + nb * 32 + o;
+        if (p < a.P && oc < a.Cout) {
+          float x = Cs[o * (TMW + 1) + r];
+          if (a.relu) x = fmaxf(x, 0.f);
+          out[((size_t)b * a.Cout + oc) * HWo + hw] = from_f32<TO>(x);
+        }
+      }
+      wave_lds_sync();
     }
   }
 }
@@ -927,6 +969,7 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
   a.out_nhwc = p->out_layout == GANET_NHWC;
   a.relu = p->fuse_relu;
   a.points = p->offset_is_points;
+  a.ablate = p->reserved[0];
   a.P = (long long)p->B * pl.Ho * pl.Wo;
 
   if (pl.ta == GANET_F32)
