@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="profiling only")
+    ap.add_argument("--algo", type=int, default=0,
+                    help="LFA algorithm: 0 auto, 1 sample-then-contract, 2 contract-then-sample")
     ap.add_argument("--pts", default="synthetic", choices=["synthetic", "zero"])
     ap.add_argument("--overlap-copy", action="store_true",
                     help="copy the lane lists D2H on a second stream")
@@ -188,7 +190,7 @@ def main():
                  thr=cfg["thr"], root_thr=cfg["root_thr"], cluster_thr=T, by_center_thr=T,
                  max_kpts=min(H * W, 4096 if cfg["lanes"] > 4 else 1024),
                  max_centers=256, overlap_copy=args.overlap_copy,
-                 ablate=args.ablate)
+                 ablate=args.ablate, algo=args.algo)
     if args.pts == "zero":
         d["pts"].zero_()
     hp.set_weight(d["w"])

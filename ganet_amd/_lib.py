@@ -34,8 +34,8 @@ class DcnParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "Cin", "H", "W", "Cout", "kH", "kW", "sH", "sW", "pH", "pW", "dH",
         "dW", "groups", "deformable_groups", "dtype", "x_layout", "out_layout",
-        "mfma_bf16", "fuse_relu", "offset_is_points", "weight_is_packed")] + [
-        ("reserved", ctypes.c_int32 * 2)]
+        "mfma_bf16", "fuse_relu", "offset_is_points", "weight_is_packed",
+        "algo", "debug")]
 
 
 class DecodeParams(ctypes.Structure):

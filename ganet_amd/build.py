@@ -19,7 +19,7 @@ COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17",
           "-Wall", "-Wno-unused-function"]
 # decode.hip must round like numpy / CPython: no fused multiply-add contraction.
 PER_FILE = {"decode.hip": ["-ffp-contract=off"]}
-SOURCES = ["api.hip", "decode.hip", "deform_conv.hip"]
+SOURCES = ["api.hip", "decode.hip", "deform_conv.hip", "deform_conv_cts.hip"]
 
 
 def _newer(a, b):
@@ -30,7 +30,7 @@ def build_lib(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DGANET_ABLATE"] if os.environ.get("GANET_ABLATE") else []  # profiling build
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = [os.path.join(ROOT, "include", "ganet_hip.h"),
+    headers = [os.path.join(ROOT, "include", "ganet_hip.h"), os.path.join(CSRC, "dcn_device.h"),
                os.path.join(CSRC, "common.h")]
     objs, relink = [], force or not os.path.exists(LIB)
     for src in SOURCES:

@@ -29,169 +29,11 @@
 //   epilogue: optional bias / ReLU, NHWC direct from the accumulators or NCHW
 //   through an LDS transpose so that stores stay coalesced.
 
-#include <type_traits>
-
-#include "common.h"
+#include "dcn_device.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-struct bf16_t {
-  unsigned short v;
-};
-typedef _Float16 f16_t;
-
-__device__ __forceinline__ float to_f32(float v) { return v; }
-__device__ __forceinline__ float to_f32(bf16_t v) {
-  return __uint_as_float(((unsigned int)v.v) << 16);
-}
-__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
-
-template <typename T>
-__device__ __forceinline__ T from_f32(float v);
-template <>
-__device__ __forceinline__ float from_f32<float>(float v) {
-  return v;
-}
-template <>
-__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
-  // plain cast: round-to-nearest-even, NaN stays NaN (v_cvt_pk_bf16_f32)
-  __bf16 b = (__bf16)v;
-  bf16_t r;
-  r.v = __builtin_bit_cast(unsigned short, b);
-  return r;
-}
-template <>
-__device__ __forceinline__ f16_t from_f32<f16_t>(float v) {
-  return (f16_t)v;
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define GANET_GLOBAL __attribute__((address_space(1)))
-
-// Pointers that reach a kernel inside a by-value struct are generic ("flat") to
-// the compiler; these casts give it global_load/global_store_dwordx4.
-__device__ __forceinline__ u32x4 ldg128(const void *p) {
-  return *(const GANET_GLOBAL u32x4 *)(p);
-}
-__device__ __forceinline__ float ldg_f32(const float *p) {
-  return *(const GANET_GLOBAL float *)(p);
-}
-
-// 16-byte piece <-> floats
-template <typename TA>
-struct PieceCvt;
-template <>
-struct PieceCvt<float> {
-  static constexpr int N = 4;
-  __device__ static __forceinline__ void unpack(const u32x4 &u, float *f) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(u[i]);
-  }
-  __device__ static __forceinline__ u32x4 pack(const float *f) {
-    u32x4 u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = __float_as_uint(f[i]);
-    return u;
-  }
-};
-template <>
-struct PieceCvt<bf16_t> {
-  static constexpr int N = 8;
-  __device__ static __forceinline__ void unpack(const u32x4 &u, float *f) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f[2 * i] = __uint_as_float(u[i] << 16);
-      f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
-    }
-  }
-  __device__ static __forceinline__ u32x4 pack(const float *f) {
-    bf16x8 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];  // RNE, NaN-preserving
-    return __builtin_bit_cast(u32x4, v);
-  }
-};
-template <>
-struct PieceCvt<f16_t> {
-  static constexpr int N = 8;
-  __device__ static __forceinline__ void unpack(const u32x4 &u, float *f) {
-    const f16x8 v = __builtin_bit_cast(f16x8, u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
-  }
-  __device__ static __forceinline__ u32x4 pack(const float *f) {
-    f16x8 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (_Float16)f[i];
-    return __builtin_bit_cast(u32x4, v);
-  }
-};
-
-constexpr int TN = 64;        // output channels per workgroup
-constexpr int TM_MAX = 256;   // largest pixel tile of a workgroup (8 waves x 32)
-constexpr int CHUNK_BYTES_MAX = 256;
-constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond any buffer window: reads 0
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct DcnArgs {
-  const void *xh;       // NHWC feature map, Cp channels per pixel
-  const float *offset;  // [B][dg*2*T][Ho][Wo]
-  const float *mask;    // [B][dg*T][Ho][Wo] or nullptr
-  const void *wp;       // packed weights [T][CoutP][Cp]
-  const void *bias;     // [Cout] or nullptr
-  void *out;
-  int B, H, W, Cp, Ho, Wo, Cout, CoutP;
-  int kH, kW, sH, sW, pH, pW, dH, dW;
-  int dg, cpg;          // deformable groups, channels per group (of Cp)
-  int out_nhwc, relu, points;
-  int ablate;           // GANET_ABLATE builds only: bit0 skip MFMAs, bit1 skip gather loads
-  long long P;          // B*Ho*Wo
-};
-
-// ---- MFMA wrappers: one 32x32 accumulator, K-slab of `EPL` elements per lane ---
-template <typename TA>
-struct Mma;
-
-template <>
-struct Mma<float> {
-  // 16 B = 4 fp32 per lane per operand -> four 32x32x2 steps.
-  // lane (i = l&31, h = l>>5) supplies A[i][k=h] and B[k=h][j=i]; with the lane
-  // reading channels [8q+4h, 8q+4h+4) of its row, step m contracts channels
-  // 8q+m (h=0) and 8q+4+m (h=1) on both operands alike.
-  typedef f32x4 frag;
-  __device__ static __forceinline__ void mma(const frag &a, const frag &b,
-                                             f32x16 &c) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m], c, 0, 0, 0);
-  }
-};
-
-template <>
-struct Mma<bf16_t> {
-  // 16 B = 8 bf16 per lane: lane (r, h) holds A[r][8h+j], B[8h+j][r], j = 0..7.
-  typedef bf16x8 frag;
-  __device__ static __forceinline__ void mma(const frag &a, const frag &b,
-                                             f32x16 &c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-
-template <>
-struct Mma<f16_t> {
-  typedef f16x8 frag;
-  __device__ static __forceinline__ void mma(const frag &a, const frag &b,
-                                             f32x16 &c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
+using namespace ganet_dcn;
 
 // Bilinear blend of four 16-byte pieces (one per corner) with per-pixel weights,
 // two channels per instruction (v_pk_mul/fma_f32).
@@ -723,7 +565,8 @@ struct Plan {
   int kc;        // channel chunk (elements)
   int Cp, CoutP;
   bool copy_x;   // a channel-last (and/or converted, padded) copy of x is made
-  size_t xh_bytes, wp_bytes;
+  bool cts;      // contract-then-sample path (deform_conv_cts.hip)
+  size_t xh_bytes, wp_bytes, y_bytes;
 };
 
 size_t dtype_size(int dt) { return dt == GANET_F32 ? 4 : 2; }
@@ -793,6 +636,11 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
                             : 0;
   pl->wp_bytes = ganet_align_up(
       (size_t)pl->T * pl->CoutP * pl->Cp * dtype_size(pl->ta), 256);
+  // Sampling and contraction commute; contract first when that shrinks the rows
+  // that have to be gathered and blended (Cout < Cin, as in the LFA).
+  pl->cts = cts_applicable(p, pl->Cp, pl->CoutP) && p->algo != 1;
+  if (p->algo == 2 && !pl->cts) return GANET_ERR_UNSUPPORTED;
+  pl->y_bytes = pl->cts ? cts_y_bytes(p, pl->CoutP, pl->ta) : 0;
   return GANET_OK;
 }
 
@@ -867,7 +715,7 @@ extern "C" int ganet_dcn_out_size(int in, int pad, int dilation, int k,
 extern "C" size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p) {
   Plan pl;
   if (make_plan(p, &pl) != GANET_OK) return 0;
-  return pl.xh_bytes + (p->weight_is_packed ? 0 : pl.wp_bytes);
+  return pl.xh_bytes + pl.y_bytes + (p->weight_is_packed ? 0 : pl.wp_bytes);
 }
 
 extern "C" size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p) {
@@ -917,14 +765,17 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
   // (deform_conv_cuda.cpp:127); the modules pad before calling (deform_conv.py:301-317)
   if (!mask && (p->H < p->kH || p->W < p->kW)) return GANET_ERR_BAD_SHAPE;
   if (bias && !mask) return GANET_ERR_BAD_SHAPE;  // DCNv1 has no bias (deform_conv.py:205)
-  const size_t need = pl.xh_bytes + (p->weight_is_packed ? 0 : pl.wp_bytes);
+  const size_t need = pl.xh_bytes + pl.y_bytes + (p->weight_is_packed ? 0 : pl.wp_bytes);
   if (need > 0 && (workspace_bytes < need || !workspace))
     return GANET_ERR_WORKSPACE;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   void *xh = pl.copy_x ? static_cast<void *>(ws) : nullptr;
-  const void *wp = p->weight_is_packed ? weight : static_cast<const void *>(ws + pl.xh_bytes);
+  void *ybuf = ws + pl.xh_bytes;
+  const void *wp = p->weight_is_packed
+                       ? weight
+                       : static_cast<const void *>(ws + pl.xh_bytes + pl.y_bytes);
 
   if (pl.copy_x) {
     if (p->dtype == GANET_F32 && pl.ta == GANET_F32)
@@ -938,8 +789,12 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
   if (!p->weight_is_packed &&
-      pack_weight_dispatch(p, pl, weight, ws + pl.xh_bytes, s) != GANET_OK)
+      pack_weight_dispatch(p, pl, weight, ws + pl.xh_bytes + pl.y_bytes, s) != GANET_OK)
     return GANET_ERR_HIP;
+
+  if (pl.cts)
+    return cts_forward(pl.copy_x ? xh : x, offset, mask, wp, bias, out, p, pl.ta, pl.kc,
+                       pl.Cp, pl.CoutP, pl.Ho, pl.Wo, ybuf, s);
 
   DcnArgs a;
   a.xh = pl.copy_x ? xh : x;
@@ -969,7 +824,7 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
   a.out_nhwc = p->out_layout == GANET_NHWC;
   a.relu = p->fuse_relu;
   a.points = p->offset_is_points;
-  a.ablate = p->reserved[0];
+  a.ablate = p->debug;
   a.P = (long long)p->B * pl.Ho * pl.Wo;
 
   if (pl.ta == GANET_F32)

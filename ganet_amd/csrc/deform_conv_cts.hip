@@ -1,0 +1,469 @@
+// Deformable convolution forward, "contract-then-sample" form, for gfx950 (MI355X).
+//
+// Bilinear sampling and the channel contraction are both linear, so they commute:
+//
+//   out[p][o] = sum_t sum_c W[o][c][t] * sample(x[:, c], pos(p, t))          (reference order:
+//                 deformable_im2col + addmm_, deform_conv_cuda.cpp:222-236)
+//             = sum_t sample(Y_t[:, o], pos(p, t)),   Y_t[q][o] = sum_c x[q][c] * W[o][c][t]
+//
+// When Cout < Cin (the LFA: 256 -> 64) the second form blends 4 corners x Cout values
+// per (pixel, tap) instead of 4 x Cin, and gathers Cout-wide rows instead of Cin-wide
+// ones: 4x less VALU and 4x less L2->L1 gather traffic, which is what bounds the fused
+// sample-then-contract kernel (profiles/r01_ablation.txt).  The price is the
+// intermediate Y[pixel][tap][Cout]; the host loop walks the batch in chunks whose Y
+// stays resident in the 256 MiB Infinity Cache between the two kernels, so HBM still
+// sees x, the offsets and the output once.
+//
+//   cts_gemm_kernel    Y = X * Wq^T  on the matrix cores: every wavefront keeps the A
+//                      fragments of its 32 pixels in registers and walks the N = T*Cout
+//                      axis in 64-column slices; the weight slice is double-buffered in LDS.
+//   cts_sample_kernel  per output pixel: coordinates once per tap (the lanes of a pixel
+//                      split the taps and share them through LDS), 4 buffer loads of
+//                      16 B per lane and tap (a corner outside the map reads 0 by the
+//                      buffer bounds check), fp32 blend/accumulate, bias, ReLU, store.
+//
+// Arithmetic of the sampling position and weights: deform_conv_cuda_kernel.cu:84-115,
+// 218-229 (and :604-627 for the DCNv2 mask), unchanged.
+
+#include "dcn_device.h"
+
+namespace ganet_dcn {
+
+namespace {
+
+constexpr int GEMM_WAVES = 8;
+constexpr int GEMM_ROWS = GEMM_WAVES * 32;
+constexpr int SAMPLE_WAVES = 4;
+constexpr int TAP_BLOCK = 16;   // taps whose coordinates sit in LDS at a time
+
+// ---- Y = X * Wq^T -------------------------------------------------------------
+// x [M][Cp], wq [N][Cp] (N multiple of 64), y [M][N].  KH channels of a row are held
+// as A fragments in registers (64 VGPRs); Cp / KH passes over K when Cp > KH.
+template <typename TA, typename TY, int KH>
+__global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
+    const TA *__restrict__ x, const TA *__restrict__ wq, TY *__restrict__ y,
+    long long M, int Cp, int N) {
+  constexpr int ES = sizeof(TA);
+  constexpr int EPL = 16 / ES;
+  constexpr int NQ = KH / (2 * EPL);          // 16-byte fragments per lane and K chunk
+  constexpr int LDB = KH + EPL;               // +16 B: conflict-free ds_read_b128
+  constexpr int B_BYTES = 64 * LDB * ES;
+  constexpr int YROW = 64 * sizeof(TY) + 16;  // staged output row (bytes)
+  constexpr int NT = GEMM_WAVES * 64;
+  typedef typename Mma<TA>::frag frag_t;
+  __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * B_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char s_y[GEMM_WAVES * 32 * YROW];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const long long m0 = (long long)blockIdx.x * GEMM_ROWS + wid * 32;
+  const long long row = (m0 + i < M) ? m0 + i : M - 1;
+  const TA *xrow = x + row * Cp + h * EPL;
+
+  const int kchunks = Cp / KH;
+  const int nslices = N / 64;
+  const int total = nslices * kchunks;
+
+  constexpr int BPIECES = 64 * (KH / EPL);
+  constexpr int BPT = BPIECES / NT;
+  static_assert(BPIECES % NT == 0, "weight slice must split evenly over the threads");
+  u32x4 breg[BPT];
+  auto load_b = [&](int it) {
+    const int n = it / kchunks, kc = it - n * kchunks;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NT;
+      const int r = q / (KH / EPL), pc = q - r * (KH / EPL);
+      breg[j] = ldg128(wq + ((size_t)(n * 64 + r) * Cp + kc * KH + pc * EPL));
+    }
+  };
+  auto store_b = [&](int buf) {
+    TA *Bs = reinterpret_cast<TA *>(s_b + buf * B_BYTES);
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NT;
+      const int r = q / (KH / EPL), pc = q - r * (KH / EPL);
+      *reinterpret_cast<u32x4 *>(Bs + r * LDB + pc * EPL) = breg[j];
+    }
+  };
+
+  frag_t fa[NQ];
+  auto load_a = [&](int kc) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      fa[q] = __builtin_bit_cast(frag_t, ldg128(xrow + kc * KH + q * 2 * EPL));
+  };
+
+  load_b(0);
+  load_a(0);
+  store_b(0);
+
+  f32x16 acc0, acc1;
+  for (int it = 0; it < total; ++it) {
+    const int n = it / kchunks, kc = it - n * kchunks;
+    __syncthreads();  // slice `it` is in its buffer; the other buffer is free again
+    if (it + 1 < total) load_b(it + 1);
+    if (kchunks > 1 && it > 0) load_a(kc);
+    if (kc == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.f;
+        acc1[r] = 0.f;
+      }
+    }
+    {
+      const TA *Bs = reinterpret_cast<const TA *>(s_b + (it & 1) * B_BYTES);
+      const TA *brow0 = Bs + i * LDB + h * EPL;
+      const TA *brow1 = brow0 + 32 * LDB;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const frag_t fb0 = *reinterpret_cast<const frag_t *>(brow0 + q * 2 * EPL);
+        const frag_t fb1 = *reinterpret_cast<const frag_t *>(brow1 + q * 2 * EPL);
+        Mma<TA>::mma(fa[q], fb0, acc0);
+        Mma<TA>::mma(fa[q], fb1, acc1);
+      }
+    }
+    if (it + 1 < total) store_b((it + 1) & 1);
+    if (kc == kchunks - 1) {
+      // 32 x 64 tile -> the wave's LDS rows -> 16-byte stores of whole 128/256-B rows
+      unsigned char *ys = s_y + wid * 32 * YROW;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        TY *yr = reinterpret_cast<TY *>(ys + rr * YROW);
+        yr[i] = from_f32<TY>(acc0[r]);
+        yr[32 + i] = from_f32<TY>(acc1[r]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      constexpr int LPR = 64 * sizeof(TY) / 16;   // lanes per row
+      constexpr int RPP = 64 / LPR;               // rows per pass
+      const int pc = lane % LPR, rq = lane / LPR;
+#pragma unroll
+      for (int ps = 0; ps < 32 / RPP; ++ps) {
+        const int rr = ps * RPP + rq;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
+        if (m0 + rr < M)
+          *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(
+              y + (m0 + rr) * N + (size_t)n * 64) + pc * 16) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
+// ---- out = sum over taps of bilinear samples of Y -----------------------------------
+struct SampleArgs {
+  const void *y;        // [nimg*H*W][T*CoutP], first image of the chunk at row 0
+  const float *offset;  // [B][2T][Ho][Wo]  (whole batch)
+  const float *mask;    // [B][T][Ho][Wo] or nullptr
+  const void *bias;     // [Cout] or nullptr
+  void *out;            // whole batch
+  int img0, nimg;       // images of this chunk
+  int H, W, Ho, Wo, Cout, CoutP, T;
+  int kW, sH, sW, pH, pW, dH, dW;
+  int out_nhwc, relu, points;
+};
+
+// one 16-byte piece of a corner row, weight w, into fp32 accumulators
+template <typename TY>
+__device__ __forceinline__ void acc_piece(const u32x4 &v, float w, f32x2 *acc);
+template <>
+__device__ __forceinline__ void acc_piece<float>(const u32x4 &v, float w, f32x2 *acc) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x2 d = {__uint_as_float(v[2 * j]), __uint_as_float(v[2 * j + 1])};
+    acc[j] = d * w + acc[j];
+  }
+}
+template <>
+__device__ __forceinline__ void acc_piece<bf16_t>(const u32x4 &v, float w, f32x2 *acc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 d = {__uint_as_float(v[j] << 16), __uint_as_float(v[j] & 0xffff0000u)};
+    acc[j] = d * w + acc[j];
+  }
+}
+template <>
+__device__ __forceinline__ void acc_piece<f16_t>(const u32x4 &v, float w, f32x2 *acc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned int u = v[j];
+    const _Float16 lo = __builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+    const _Float16 hi = __builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+    const f32x2 d = {(float)lo, (float)hi};
+    acc[j] = d * w + acc[j];
+  }
+}
+
+template <typename TY, typename TO>
+__global__ __launch_bounds__(SAMPLE_WAVES * 64) void cts_sample_kernel(SampleArgs a) {
+  constexpr int ESY = sizeof(TY);
+  constexpr int EPL = 16 / ESY;            // channels per lane
+  constexpr int LPX = 64 / EPL;            // lanes per pixel (64-channel block)
+  constexpr int PPW = 64 / LPX;            // pixels per wavefront pass
+  constexpr int NACC = EPL / 2;
+  __shared__ __attribute__((aligned(16))) unsigned int s_off[SAMPLE_WAVES][PPW][TAP_BLOCK][4];
+  __shared__ __attribute__((aligned(16))) float s_w[SAMPLE_WAVES][PPW][TAP_BLOCK][4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pj = lane / LPX, piece = lane % LPX;
+  const int cb = blockIdx.y;               // 64-channel block of the output
+  const int HWo = a.Ho * a.Wo;
+  const long long P = (long long)a.nimg * HWo;
+  const int N = a.T * a.CoutP;
+  const unsigned px_bytes = (unsigned)N * ESY;            // one pixel row of Y
+  const unsigned row_bytes = (unsigned)a.W * px_bytes;
+  const unsigned img_bytes = (unsigned)a.H * row_bytes;
+  const size_t y_bytes = (size_t)a.nimg * img_bytes;
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(a.y), 0, (int)(y_bytes < 0x7fffffffull ? y_bytes : 0x7fffffffull),
+      0x00020000);
+  const unsigned lane_off = (unsigned)((cb * 64 + piece * EPL) * ESY);
+  const TO *bias = static_cast<const TO *>(a.bias);
+  TO *out = static_cast<TO *>(a.out);
+
+  const long long ngroups = (P + PPW - 1) / PPW;
+  for (long long grp = (long long)blockIdx.x * SAMPLE_WAVES + wid; grp < ngroups;
+       grp += (long long)gridDim.x * SAMPLE_WAVES) {
+    const long long p = grp * PPW + pj;
+    const bool valid = p < P;
+    const int bl = valid ? (int)(p / HWo) : 0;            // image within the chunk
+    const int hw = valid ? (int)(p - (long long)bl * HWo) : 0;
+    const int ho = hw / a.Wo, wo = hw - ho * a.Wo;
+    const int b = a.img0 + bl;
+
+    f32x2 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = f32x2{0.f, 0.f};
+
+    for (int t0 = 0; t0 < a.T; t0 += TAP_BLOCK) {
+      const int nt = min(TAP_BLOCK, a.T - t0);
+      // the LPX lanes of a pixel split the taps of this block
+      for (int tt = piece; tt < nt; tt += LPX) {
+        const int t = t0 + tt;
+        const int ti = t / a.kW, tj = t - ti * a.kW;
+        unsigned c1 = OOB_OFFSET, c2 = OOB_OFFSET, c3 = OOB_OFFSET, c4 = OOB_OFFSET;
+        float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+        if (valid) {
+          const float *op = a.offset + ((size_t)b * 2 * a.T + 2 * t) * HWo + hw;
+          float off_h = ldg_f32(op);
+          float off_w = ldg_f32(op + HWo);
+          float mk = 1.f;
+          if (a.mask) mk = ldg_f32(a.mask + ((size_t)b * a.T + t) * HWo + hw);
+          if (a.points)  // dcn_offset = pts - base  (lanepoints_conv.py:63-74,170)
+            off_w = off_w - (float)(tj - a.pW);
+          const float h_im = (float)(ho * a.sH - a.pH + ti * a.dH) + off_h;
+          const float w_im = (float)(wo * a.sW - a.pW + tj * a.dW) + off_w;
+          if (h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W) {
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+            const float hh = 1.f - lh, hw_ = 1.f - lw;
+            w1 = hh * hw_ * mk;
+            w2 = hh * lw * mk;
+            w3 = lh * hw_ * mk;
+            w4 = lh * lw * mk;
+            const unsigned base = (unsigned)bl * img_bytes + (unsigned)h_low * row_bytes +
+                                  (unsigned)w_low * px_bytes +
+                                  (unsigned)t * (unsigned)(a.CoutP * ESY);
+            const bool hl = h_low >= 0, hh_ok = h_high <= a.H - 1;
+            const bool wl = w_low >= 0, wh_ok = w_high <= a.W - 1;
+            if (hl && wl) c1 = base;
+            if (hl && wh_ok) c2 = base + px_bytes;
+            if (hh_ok && wl) c3 = base + row_bytes;
+            if (hh_ok && wh_ok) c4 = base + row_bytes + px_bytes;
+          }
+        }
+        *reinterpret_cast<uint4 *>(s_off[wid][pj][tt]) = make_uint4(c1, c2, c3, c4);
+        *reinterpret_cast<float4 *>(s_w[wid][pj][tt]) = make_float4(w1, w2, w3, w4);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+      for (int tt = 0; tt < nt; ++tt) {
+        const uint4 cx = *reinterpret_cast<const uint4 *>(s_off[wid][pj][tt]);
+        const float4 w = *reinterpret_cast<const float4 *>(s_w[wid][pj][tt]);
+        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.x + lane_off, 0, 0);
+        const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.y + lane_off, 0, 0);
+        const u32x4 v3 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.z + lane_off, 0, 0);
+        const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.w + lane_off, 0, 0);
+        acc_piece<TY>(v1, w.x, acc);
+        acc_piece<TY>(v2, w.y, acc);
+        acc_piece<TY>(v3, w.z, acc);
+        acc_piece<TY>(v4, w.w, acc);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    if (valid) {
+      const int c0 = cb * 64 + piece * EPL;
+      float r[EPL];
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        r[2 * j] = acc[j].x;
+        r[2 * j + 1] = acc[j].y;
+      }
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        if (bias && c0 + e < a.Cout) r[e] += to_f32(bias[c0 + e]);
+        if (a.relu) r[e] = fmaxf(r[e], 0.f);
+      }
+      const long long pg = (long long)b * HWo + hw;   // pixel index in the whole batch
+      if (a.out_nhwc) {
+        TO *dst = out + pg * a.Cout + c0;
+        if (c0 + EPL <= a.Cout && (a.Cout * sizeof(TO)) % 16 == 0 && sizeof(TO) == ESY) {
+          u32x4 pk;
+          TO tmp[EPL];
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) tmp[e] = from_f32<TO>(r[e]);
+          __builtin_memcpy(&pk, tmp, 16);
+          *reinterpret_cast<u32x4 *>(dst) = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e)
+            if (c0 + e < a.Cout) dst[e] = from_f32<TO>(r[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+          if (c0 + e < a.Cout)
+            out[((size_t)b * a.Cout + c0 + e) * HWo + hw] = from_f32<TO>(r[e]);
+      }
+    }
+  }
+}
+
+template <typename TA, typename TY>
+void launch_gemm(int kh, const void *x, const void *wq, void *y, long long M, int Cp,
+                 int N, hipStream_t s) {
+  constexpr int KBIG = sizeof(TA) == 4 ? 128 : 256;
+  dim3 grid((unsigned)((M + GEMM_ROWS - 1) / GEMM_ROWS));
+  dim3 block(GEMM_WAVES * 64);
+  const TA *xx = static_cast<const TA *>(x);
+  const TA *ww = static_cast<const TA *>(wq);
+  TY *yy = static_cast<TY *>(y);
+  if (kh == KBIG)
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+  else if (kh == KBIG / 2)
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 2>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+  else
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 4>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+}
+
+template <typename TY, typename TO>
+void launch_sample(const SampleArgs &a, hipStream_t s) {
+  constexpr int PPW = 64 / (64 / (16 / (int)sizeof(TY)));
+  const long long P = (long long)a.nimg * a.Ho * a.Wo;
+  const long long groups = (P + PPW - 1) / PPW;
+  long long blocks = (groups + SAMPLE_WAVES - 1) / SAMPLE_WAVES;
+  // a few pixel groups per wavefront amortise the launch; keep every CU busy
+  const long long cap = 256ll * 16;
+  if (blocks > cap) blocks = cap;
+  dim3 grid((unsigned)blocks, (unsigned)(a.CoutP / 64));
+  hipLaunchKernelGGL((cts_sample_kernel<TY, TO>), grid, dim3(SAMPLE_WAVES * 64), 0, s, a);
+}
+
+}  // namespace
+
+// Applicable when the commuted order is cheaper and its assumptions hold: one
+// deformable group (one Y per tap) and fewer output than input channels.
+bool cts_applicable(const ganet_dcn_params *p, int Cp, int CoutP) {
+  // fp32: the per-tap GEMM alone costs what the fused kernel costs in total
+  // (fp32 MFMA runs at the vector rate), so only the 16-bit paths commute.
+  if (p->dtype == GANET_F32 && !p->mfma_bf16 && p->algo != 2) return false;
+  return p->deformable_groups == 1 && p->groups == 1 && 2 * CoutP <= Cp &&
+         p->sH == 1 && p->sW == 1 && p->kH * p->kW <= 64;
+}
+
+// images per chunk: Y of one chunk stays well inside the 256 MiB Infinity Cache, and
+// the chunks are balanced so that no launch is left with a sliver of the batch
+int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta) {
+  const size_t es = ta == GANET_F32 ? 4 : 2;
+  const size_t per_img = (size_t)p->H * p->W * p->kH * p->kW * CoutP * es;
+  const size_t budget = 144ull << 20;
+  size_t nmax = budget / (per_img ? per_img : 1);
+  if (nmax < 1) nmax = 1;
+  if (nmax > (size_t)p->B) nmax = p->B;
+  const size_t chunks = ((size_t)p->B + nmax - 1) / nmax;
+  return (int)(((size_t)p->B + chunks - 1) / chunks);
+}
+
+size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta) {
+  const size_t es = ta == GANET_F32 ? 4 : 2;
+  const size_t per_img = (size_t)p->H * p->W * p->kH * p->kW * CoutP * es;
+  return ganet_align_up(per_img * cts_chunk_images(p, CoutP, ta), 256);
+}
+
+// xh: NHWC map in arithmetic dtype `ta` with Cp channels; wq: packed weights
+// [T][CoutP][Cp] (same layout the fused kernel uses); ybuf: cts_y_bytes() of scratch.
+int cts_forward(const void *xh, const float *offset, const float *mask, const void *wq,
+                const void *bias, void *out, const ganet_dcn_params *p, int ta, int kc,
+                int Cp, int CoutP, int Ho, int Wo, void *ybuf, hipStream_t s) {
+  const int T = p->kH * p->kW;
+  const int N = T * CoutP;
+  const size_t es = ta == GANET_F32 ? 4 : 2;
+  const size_t img_y = (size_t)p->H * p->W * N * es;
+  if (img_y >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
+  const int nb = cts_chunk_images(p, CoutP, ta);
+  if ((size_t)nb * img_y >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
+  for (int img0 = 0; img0 < p->B; img0 += nb) {
+    const int nimg = (p->B - img0) < nb ? (p->B - img0) : nb;
+    const long long M = (long long)nimg * p->H * p->W;
+    const unsigned char *xc =
+        static_cast<const unsigned char *>(xh) + (size_t)img0 * p->H * p->W * Cp * es;
+    if (ta == GANET_F32)
+      launch_gemm<float, float>(kc, xc, wq, ybuf, M, Cp, N, s);
+    else if (ta == GANET_BF16)
+      launch_gemm<bf16_t, bf16_t>(kc, xc, wq, ybuf, M, Cp, N, s);
+    else
+      launch_gemm<f16_t, f16_t>(kc, xc, wq, ybuf, M, Cp, N, s);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+
+    SampleArgs a;
+    a.y = ybuf;
+    a.offset = offset;
+    a.mask = mask;
+    a.bias = bias;
+    a.out = out;
+    a.img0 = img0;
+    a.nimg = nimg;
+    a.H = p->H;
+    a.W = p->W;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.Cout = p->Cout;
+    a.CoutP = CoutP;
+    a.T = T;
+    a.kW = p->kW;
+    a.sH = p->sH;
+    a.sW = p->sW;
+    a.pH = p->pH;
+    a.pW = p->pW;
+    a.dH = p->dH;
+    a.dW = p->dW;
+    a.out_nhwc = p->out_layout == GANET_NHWC;
+    a.relu = p->fuse_relu;
+    a.points = p->offset_is_points;
+    if (ta == GANET_F32)
+      launch_sample<float, float>(a, s);
+    else if (ta == GANET_BF16 && p->dtype == GANET_F32)
+      launch_sample<bf16_t, float>(a, s);
+    else if (ta == GANET_BF16)
+      launch_sample<bf16_t, bf16_t>(a, s);
+    else
+      launch_sample<f16_t, f16_t>(a, s);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+  }
+  return GANET_OK;
+}
+
+}  // namespace ganet_dcn

@@ -73,7 +73,7 @@ def _packed_weight(L, weight, p):
 def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
                         dilation=(1, 1), groups=1, deformable_groups=1,
                         mask=None, bias=None, fuse_relu=False,
-                        offset_is_points=False, mfma_bf16=None):
+                        offset_is_points=False, mfma_bf16=None, algo=0):
     """Raw forward on the HIP library.  `input` NCHW (contiguous or
     channels_last) on a GPU; returns a tensor of the same memory format."""
     if not input.is_cuda:
@@ -113,6 +113,7 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
     p.mfma_bf16 = 1 if (use_bf16 and input.dtype == torch.float32) else 0
     p.fuse_relu = 1 if fuse_relu else 0
     p.offset_is_points = 1 if offset_is_points else 0
+    p.algo = algo
     Ho = L.ganet_dcn_out_size(H, p.pH, p.dH, kH, p.sH)
     Wo = L.ganet_dcn_out_size(W, p.pW, p.dW, kW, p.sW)
     if Ho < 1 or Wo < 1:

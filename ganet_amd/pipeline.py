@@ -27,7 +27,7 @@ class HotPath(object):
                  by_center_thr=5.0, max_kpts=1024, max_centers=128,
                  channels_last=True, mfma_bf16=False, fuse_relu=True,
                  offset_is_points=True, expect_kpts=192, expect_centers=16,
-                 overlap_copy=False, ablate=0):
+                 overlap_copy=False, ablate=0, algo=0):
         self.L = _lib.lib()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.B, self.H, self.W, self.K = B, H, W, K
@@ -44,7 +44,8 @@ class HotPath(object):
         p.fuse_relu = 1 if fuse_relu else 0
         p.offset_is_points = 1 if offset_is_points else 0
         p.weight_is_packed = 1
-        p.reserved[0] = ablate   # profiling only (see csrc/deform_conv.hip)
+        p.debug = ablate         # profiling builds only (see csrc/deform_conv.hip)
+        p.algo = algo
         self.p = p
         with torch.cuda.device(self.device):
             nb = self.L.ganet_deform_conv_packed_weight_bytes(ctypes.byref(p))

@@ -88,7 +88,12 @@ typedef struct {
   int32_t weight_is_packed; /* 1 = `weight` was produced by
                                ganet_deform_conv_pack_weight for these params
                                (inference: pack once, not per call) */
-  int32_t reserved[2];
+  int32_t algo;             /* 0 = choose automatically; 1 = sample-then-contract
+                               (one fused gather+blend+MFMA kernel);
+                               2 = contract-then-sample (per-tap GEMM into a
+                               cache-resident scratch, then sampling; needs one
+                               deformable group, stride 1, 2*Cout <= Cin) */
+  int32_t debug;            /* must be 0 (ablation bits of profiling builds) */
 } ganet_dcn_params;
 
 /* Output spatial size rule of the reference

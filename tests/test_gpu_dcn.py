@@ -82,6 +82,56 @@ def test_16bit_generic_shapes(case, dtype):
         assert rel_err(got, ref) <= TOL_16
 
 
+CTS_CASES = [
+    # shapes where contract-then-sample applies (one deformable group, stride 1, 2*Cout <= Cin)
+    (2, 256, 12, 20, 64, 1, 7, (1, 1), (0, 3), (1, 1), 1),
+    (1, 128, 9, 13, 40, 3, 3, (1, 1), (1, 1), (1, 1), 1),     # padded Cout
+    (3, 256, 7, 9, 128, 1, 9, (1, 1), (0, 4), (1, 1), 1),     # two 64-channel output blocks
+    (1, 192, 10, 12, 20, 3, 3, (1, 1), (2, 2), (2, 2), 1),    # Cin = 3 x 64
+]
+
+
+@pytest.mark.parametrize("case", CTS_CASES)
+@pytest.mark.parametrize("algo", [1, 2])
+def test_both_algorithms_agree_with_oracle(case, algo):
+    """algo 1 = fused sample-then-contract, algo 2 = contract-then-sample."""
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w = make(*case, seed=11)
+    ref = O.deform_conv_forward(x, off, w, st, pad, dil, 1, dg, nthreads=4)
+    for cl in (False, True):
+        got = run_gpu(x, off, w, st, pad, dil, dg, channels_last=cl, algo=algo)
+        assert rel_err(got, ref) <= TOL_F32
+    xr = torch.from_numpy(x).bfloat16().float().numpy()
+    wr = torch.from_numpy(w).bfloat16().float().numpy()
+    ref16 = O.deform_conv_forward(xr, off, wr, st, pad, dil, 1, dg, nthreads=4)
+    for dtype in (torch.bfloat16, torch.float16):
+        if dtype == torch.float16:
+            xr = torch.from_numpy(x).half().float().numpy()
+            wr = torch.from_numpy(w).half().float().numpy()
+            ref16 = O.deform_conv_forward(xr, off, wr, st, pad, dil, 1, dg, nthreads=4)
+        got = run_gpu(x, off, w, st, pad, dil, dg, dtype=dtype, channels_last=True, algo=algo)
+        assert rel_err(got, ref16) <= TOL_16
+    got = run_gpu(x, off, w, st, pad, dil, dg, mfma_bf16=True, algo=algo)
+    assert rel_err(got, ref) <= TOL_16
+
+
+def test_cts_with_mask_bias_relu_and_points():
+    rng = np.random.default_rng(17)
+    B, Cin, H, W, Cout, K = 2, 256, 10, 25, 64, 7
+    x, off, w, pts = synth.lfa_inputs(B, Cin, H, W, K, Cout=Cout, seed=9)
+    mask = rng.uniform(0, 1, (B, K, H, W)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    ref = O.deform_conv_forward(x, off, w, (1, 1), (0, 3), (1, 1), mask=mask, bias=bias)
+    for algo in (1, 2):
+        got = run_gpu(x, off, w, (1, 1), (0, 3), (1, 1), mask=mask, bias=bias, algo=algo,
+                      fuse_relu=True, channels_last=True)
+        assert rel_err(got, np.maximum(ref, 0)) <= TOL_F32
+        # offsets given as the LFA's points: the kernel subtracts the base itself
+        gotp = run_gpu(x, pts, w, (1, 1), (0, 3), (1, 1), mask=mask, bias=bias, algo=algo,
+                       offset_is_points=True)
+        assert rel_err(gotp, ref) <= TOL_F32
+
+
 def test_fp32_storage_bf16_mfma():
     case = GENERIC[0]
     x, off, w = make(*case)
