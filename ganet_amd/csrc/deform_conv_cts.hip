@@ -39,10 +39,12 @@ constexpr int TAP_BLOCK = 16;   // taps whose coordinates sit in LDS at a time
 // ---- Y = X * Wq^T -------------------------------------------------------------
 // x [M][Cp], wq [N][Cp] (N multiple of 64), y [M][N].  KH channels of a row are held
 // as A fragments in registers (64 VGPRs); Cp / KH passes over K when Cp > KH.
-template <typename TA, typename TY, int KH>
+template <typename TA, typename TY, int KH, int RB>
 __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
     const TA *__restrict__ x, const TA *__restrict__ wq, TY *__restrict__ y,
     long long M, int Cp, int N) {
+  // RB 32-row blocks per wavefront: every weight fragment read from LDS feeds RB
+  // MFMAs (with RB = 1 the ds_read traffic alone equals the MFMA time).
   constexpr int ES = sizeof(TA);
   constexpr int EPL = 16 / ES;
   constexpr int NQ = KH / (2 * EPL);          // 16-byte fragments per lane and K chunk
@@ -57,9 +59,13 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
-  const long long m0 = (long long)blockIdx.x * GEMM_ROWS + wid * 32;
-  const long long row = (m0 + i < M) ? m0 + i : M - 1;
-  const TA *xrow = x + row * Cp + h * EPL;
+  const long long m0 = ((long long)blockIdx.x * GEMM_WAVES + wid) * (32 * RB);
+  const TA *xrow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const long long r = m0 + rb * 32 + i;
+    xrow[rb] = x + (r < M ? r : M - 1) * Cp + h * EPL;
+  }
 
   const int kchunks = Cp / KH;
   const int nslices = N / 64;
@@ -88,18 +94,20 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
     }
   };
 
-  frag_t fa[NQ];
+  frag_t fa[RB][NQ];
   auto load_a = [&](int kc) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      fa[q] = __builtin_bit_cast(frag_t, ldg128(xrow + kc * KH + q * 2 * EPL));
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        fa[rb][q] = __builtin_bit_cast(frag_t, ldg128(xrow[rb] + kc * KH + q * 2 * EPL));
   };
 
   load_b(0);
   load_a(0);
   store_b(0);
 
-  f32x16 acc0, acc1;
+  f32x16 acc[RB][2];
   for (int it = 0; it < total; ++it) {
     const int n = it / kchunks, kc = it - n * kchunks;
     __syncthreads();  // slice `it` is in its buffer; the other buffer is free again
@@ -107,10 +115,12 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
     if (kchunks > 1 && it > 0) load_a(kc);
     if (kc == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc0[r] = 0.f;
-        acc1[r] = 0.f;
-      }
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[rb][0][r] = 0.f;
+          acc[rb][1][r] = 0.f;
+        }
     }
     {
       const TA *Bs = reinterpret_cast<const TA *>(s_b + (it & 1) * B_BYTES);
@@ -120,38 +130,45 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
       for (int q = 0; q < NQ; ++q) {
         const frag_t fb0 = *reinterpret_cast<const frag_t *>(brow0 + q * 2 * EPL);
         const frag_t fb1 = *reinterpret_cast<const frag_t *>(brow1 + q * 2 * EPL);
-        Mma<TA>::mma(fa[q], fb0, acc0);
-        Mma<TA>::mma(fa[q], fb1, acc1);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          Mma<TA>::mma(fa[rb][q], fb0, acc[rb][0]);
+          Mma<TA>::mma(fa[rb][q], fb1, acc[rb][1]);
+        }
       }
     }
     if (it + 1 < total) store_b((it + 1) & 1);
     if (kc == kchunks - 1) {
       // 32 x 64 tile -> the wave's LDS rows -> 16-byte stores of whole 128/256-B rows
       unsigned char *ys = s_y + wid * 32 * YROW;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-        TY *yr = reinterpret_cast<TY *>(ys + rr * YROW);
-        yr[i] = from_f32<TY>(acc0[r]);
-        yr[32 + i] = from_f32<TY>(acc1[r]);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       constexpr int LPR = 64 * sizeof(TY) / 16;   // lanes per row
       constexpr int RPP = 64 / LPR;               // rows per pass
       const int pc = lane % LPR, rq = lane / LPR;
 #pragma unroll
-      for (int ps = 0; ps < 32 / RPP; ++ps) {
-        const int rr = ps * RPP + rq;
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
-        if (m0 + rr < M)
-          *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(
-              y + (m0 + rr) * N + (size_t)n * 64) + pc * 16) = v;
+      for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+          TY *yr = reinterpret_cast<TY *>(ys + rr * YROW);
+          yr[i] = from_f32<TY>(acc[rb][0][r]);
+          yr[32 + i] = from_f32<TY>(acc[rb][1][r]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+          const int rr = ps * RPP + rq;
+          const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
+          const long long mr = m0 + rb * 32 + rr;
+          if (mr < M)
+            *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(
+                y + mr * N + (size_t)n * 64) + pc * 16) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
 }
@@ -228,9 +245,17 @@ __global__ __launch_bounds__(SAMPLE_WAVES * 64) void cts_sample_kernel(SampleArg
   const TO *bias = static_cast<const TO *>(a.bias);
   TO *out = static_cast<TO *>(a.out);
 
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Every XCD walks one
+  // contiguous eighth of the pixels, so the rows of Y shared by neighbouring pixels
+  // (the next column, the next image row) are fetched into ONE L2 instead of several.
   const long long ngroups = (P + PPW - 1) / PPW;
-  for (long long grp = (long long)blockIdx.x * SAMPLE_WAVES + wid; grp < ngroups;
-       grp += (long long)gridDim.x * SAMPLE_WAVES) {
+  const long long per_xcd = (ngroups + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const long long xbeg = xcd * per_xcd;
+  const long long xend = xbeg + per_xcd < ngroups ? xbeg + per_xcd : ngroups;
+  const long long xstride = (long long)(gridDim.x >> 3) * SAMPLE_WAVES;
+  for (long long grp = xbeg + (long long)(blockIdx.x >> 3) * SAMPLE_WAVES + wid; grp < xend;
+       grp += xstride) {
     const long long p = grp * PPW + pj;
     const bool valid = p < P;
     const int bl = valid ? (int)(p / HWo) : 0;            // image within the chunk
@@ -342,21 +367,32 @@ __global__ __launch_bounds__(SAMPLE_WAVES * 64) void cts_sample_kernel(SampleArg
   }
 }
 
-template <typename TA, typename TY>
-void launch_gemm(int kh, const void *x, const void *wq, void *y, long long M, int Cp,
-                 int N, hipStream_t s) {
+template <typename TA, typename TY, int RB>
+void launch_gemm_rb(int kh, const void *x, const void *wq, void *y, long long M, int Cp,
+                    int N, hipStream_t s) {
   constexpr int KBIG = sizeof(TA) == 4 ? 128 : 256;
-  dim3 grid((unsigned)((M + GEMM_ROWS - 1) / GEMM_ROWS));
+  constexpr int ROWS = GEMM_ROWS * RB;
+  dim3 grid((unsigned)((M + ROWS - 1) / ROWS));
   dim3 block(GEMM_WAVES * 64);
   const TA *xx = static_cast<const TA *>(x);
   const TA *ww = static_cast<const TA *>(wq);
   TY *yy = static_cast<TY *>(y);
   if (kh == KBIG)
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
   else if (kh == KBIG / 2)
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 2>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 2, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
   else
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 4>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 4, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+}
+
+template <typename TA, typename TY>
+void launch_gemm(int kh, const void *x, const void *wq, void *y, long long M, int Cp,
+                 int N, hipStream_t s) {
+  // two row blocks per wavefront once that still leaves a workgroup for most CUs
+  if (M >= 160ll * GEMM_ROWS * 2)
+    launch_gemm_rb<TA, TY, 2>(kh, x, wq, y, M, Cp, N, s);
+  else
+    launch_gemm_rb<TA, TY, 1>(kh, x, wq, y, M, Cp, N, s);
 }
 
 template <typename TY, typename TO>
@@ -368,6 +404,7 @@ void launch_sample(const SampleArgs &a, hipStream_t s) {
   // a few pixel groups per wavefront amortise the launch; keep every CU busy
   const long long cap = 256ll * 16;
   if (blocks > cap) blocks = cap;
+  blocks = (blocks + 7) / 8 * 8;   // the XCD walk needs a whole number of rounds
   dim3 grid((unsigned)blocks, (unsigned)(a.CoutP / 64));
   hipLaunchKernelGGL((cts_sample_kernel<TY, TO>), grid, dim3(SAMPLE_WAVES * 64), 0, s, a);
 }
