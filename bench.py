@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch of synthetic input that is
-already resident in HBM: the fused LFA kernel (relu(DeformConv1D(x, pts - base)))
+already resident in HBM: the LFA (relu(DeformConv1D(x, pts - base)), one C-ABI call)
 followed by decode + lane grouping of the same batch and the async D2H copy of
 the compact lane lists.  Images are independent, so on N GPUs each rank owns
 its own batch of the same size (weak scaling) and NO collective is on the data
@@ -255,7 +255,9 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=hbm_achieved, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=hbm_achieved / HBM_PEAK_GBS)
-        roof.update(traffic=traffic, kernel="dcn_fused_kernel",
+        kernels = ("dcn_fused_kernel" if hp.lfa_algorithm == 1 else
+                   "cts_gemm_kernel + cts_sample_kernel (all chunk pairs of one LFA launch)")
+        roof.update(traffic=traffic, kernel=kernels, lfa_algorithm=hp.lfa_algorithm,
                     kernel_ms=lfa_ms, algorithmic_bytes=nbytes, algorithmic_flops=flops,
                     hbm_gbs=hbm_achieved, hbm_frac=hbm_achieved / HBM_PEAK_GBS,
                     mfma_tflops=mfma_achieved,

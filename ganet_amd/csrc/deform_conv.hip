@@ -718,6 +718,12 @@ extern "C" size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p) {
   return pl.xh_bytes + pl.y_bytes + (p->weight_is_packed ? 0 : pl.wp_bytes);
 }
 
+extern "C" int ganet_deform_conv_algorithm(const ganet_dcn_params *p) {
+  Plan pl;
+  if (!p || make_plan(p, &pl) != GANET_OK) return 0;
+  return pl.cts ? 2 : 1;
+}
+
 extern "C" size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p) {
   Plan pl;
   if (make_plan(p, &pl) != GANET_OK) return 0;

@@ -26,32 +26,40 @@
 // 218-229 (and :604-627 for the DCNv2 mask), unchanged.
 
 #include "dcn_device.h"
+#include <cstdlib>
 
 namespace ganet_dcn {
 
 namespace {
 
 constexpr int GEMM_WAVES = 8;
-constexpr int GEMM_ROWS = GEMM_WAVES * 32;
 constexpr int SAMPLE_WAVES = 4;
 constexpr int TAP_BLOCK = 16;   // taps whose coordinates sit in LDS at a time
 
 // ---- Y = X * Wq^T -------------------------------------------------------------
-// x [M][Cp], wq [N][Cp] (N multiple of 64), y [M][N].  KH channels of a row are held
-// as A fragments in registers (64 VGPRs); Cp / KH passes over K when Cp > KH.
+// x [M][Cp], wq [N][Cp] (N multiple of 64), y [M][N].
+//
+// A wavefront owns RB blocks of 32 rows (pixels) and keeps their KH channels in
+// registers as MFMA operands for its whole life; the workgroup walks the N axis in
+// 64-column slices whose weights are double-buffered in LDS (one barrier per slice).
+// Every weight fragment read from LDS feeds RB MFMAs: with RB = 1 the ds_read traffic
+// alone takes as long as the MFMAs.  The product is formed transposed (rows = output
+// columns, columns = pixels), so a lane ends up with 4 consecutive outputs of ONE pixel
+// per accumulator quad: it parks them in the wave's LDS rows with 8/16-byte writes
+// and whole row segments leave as 16-byte stores.
+// One 8-wave workgroup per CU (256 VGPRs); two 4-wave workgroups per CU measured the
+// same.  The next weight slice is staged through registers in two halves.
 template <typename TA, typename TY, int KH, int RB>
 __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
     const TA *__restrict__ x, const TA *__restrict__ wq, TY *__restrict__ y,
-    long long M, int Cp, int N) {
-  // RB 32-row blocks per wavefront: every weight fragment read from LDS feeds RB
-  // MFMAs (with RB = 1 the ds_read traffic alone equals the MFMA time).
+    long long M, int Cp, int N, int ablate) {
   constexpr int ES = sizeof(TA);
   constexpr int EPL = 16 / ES;
   constexpr int NQ = KH / (2 * EPL);          // 16-byte fragments per lane and K chunk
   constexpr int LDB = KH + EPL;               // +16 B: conflict-free ds_read_b128
   constexpr int B_BYTES = 64 * LDB * ES;
-  constexpr int YROW = 64 * sizeof(TY) + 16;  // staged output row (bytes)
   constexpr int NT = GEMM_WAVES * 64;
+  constexpr int YROW = 32 * sizeof(TY) + 16;  // staged half-slice row (bytes)
   typedef typename Mma<TA>::frag frag_t;
   __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * B_BYTES];
   __shared__ __attribute__((aligned(16))) unsigned char s_y[GEMM_WAVES * 32 * YROW];
@@ -72,23 +80,27 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
   const int total = nslices * kchunks;
 
   constexpr int BPIECES = 64 * (KH / EPL);
-  constexpr int BPT = BPIECES / NT;
+  constexpr int BPT = BPIECES / NT;           // 16-byte pieces per thread and slice
+  constexpr int NH = BPT % 2 == 0 ? 2 : 1;    // staged in two halves when it splits
+  constexpr int BH = BPT / NH;
   static_assert(BPIECES % NT == 0, "weight slice must split evenly over the threads");
-  u32x4 breg[BPT];
-  auto load_b = [&](int it) {
+  u32x4 breg[BH];
+  auto load_b = [&](int it, int half) {
+    if (half >= NH) return;
     const int n = it / kchunks, kc = it - n * kchunks;
 #pragma unroll
-    for (int j = 0; j < BPT; ++j) {
-      const int q = tid + j * NT;
+    for (int j = 0; j < BH; ++j) {
+      const int q = tid + (half * BH + j) * NT;
       const int r = q / (KH / EPL), pc = q - r * (KH / EPL);
       breg[j] = ldg128(wq + ((size_t)(n * 64 + r) * Cp + kc * KH + pc * EPL));
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, int half) {
+    if (half >= NH) return;
     TA *Bs = reinterpret_cast<TA *>(s_b + buf * B_BYTES);
 #pragma unroll
-    for (int j = 0; j < BPT; ++j) {
-      const int q = tid + j * NT;
+    for (int j = 0; j < BH; ++j) {
+      const int q = tid + (half * BH + j) * NT;
       const int r = q / (KH / EPL), pc = q - r * (KH / EPL);
       *reinterpret_cast<u32x4 *>(Bs + r * LDB + pc * EPL) = breg[j];
     }
@@ -103,15 +115,18 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
         fa[rb][q] = __builtin_bit_cast(frag_t, ldg128(xrow[rb] + kc * KH + q * 2 * EPL));
   };
 
-  load_b(0);
+  load_b(0, 0);
   load_a(0);
-  store_b(0);
+  store_b(0, 0);
+  load_b(0, 1);
+  store_b(0, 1);
 
   f32x16 acc[RB][2];
   for (int it = 0; it < total; ++it) {
     const int n = it / kchunks, kc = it - n * kchunks;
+    const bool more = it + 1 < total;
     __syncthreads();  // slice `it` is in its buffer; the other buffer is free again
-    if (it + 1 < total) load_b(it + 1);
+    if (more) load_b(it + 1, 0);
     if (kchunks > 1 && it > 0) load_a(kc);
     if (kc == 0) {
 #pragma unroll
@@ -128,47 +143,75 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
       const TA *brow1 = brow0 + 32 * LDB;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
+        if (q == NQ / 2 && more) {   // first half has landed behind NQ/2 MFMA steps
+          store_b((it + 1) & 1, 0);
+          load_b(it + 1, 1);
+        }
         const frag_t fb0 = *reinterpret_cast<const frag_t *>(brow0 + q * 2 * EPL);
         const frag_t fb1 = *reinterpret_cast<const frag_t *>(brow1 + q * 2 * EPL);
+#ifdef GANET_ABLATE  // profiling build only: bit0 skips the MFMAs, operands stay live
+        if (ablate & 1) {
+          asm volatile("" ::"v"(fa[0][q]), "v"(fb0), "v"(fb1));
+          continue;
+        }
+#endif
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-          Mma<TA>::mma(fa[rb][q], fb0, acc[rb][0]);
-          Mma<TA>::mma(fa[rb][q], fb1, acc[rb][1]);
+          Mma<TA>::mma(fb0, fa[rb][q], acc[rb][0]);   // rows = outputs, columns = pixels
+          Mma<TA>::mma(fb1, fa[rb][q], acc[rb][1]);
         }
       }
     }
-    if (it + 1 < total) store_b((it + 1) & 1);
+    if (more) store_b((it + 1) & 1, 1);
     if (kc == kchunks - 1) {
-      // 32 x 64 tile -> the wave's LDS rows -> 16-byte stores of whole 128/256-B rows
+#ifdef GANET_ABLATE  // bit2: keep only the first slice's stores
+      if ((ablate & 4) && n > 0) {
+        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[0][1][0]));
+        continue;
+      }
+#endif
+      // lane (i, h), registers 4g..4g+3 of tile t hold outputs t*32 + 8g + 4h + 0..3 of
+      // pixel i
       unsigned char *ys = s_y + wid * 32 * YROW;
-      constexpr int LPR = 64 * sizeof(TY) / 16;   // lanes per row
+      constexpr int LPR = 32 * sizeof(TY) / 16;   // lanes per staged row
       constexpr int RPP = 64 / LPR;               // rows per pass
       const int pc = lane % LPR, rq = lane / LPR;
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-          TY *yr = reinterpret_cast<TY *>(ys + rr * YROW);
-          yr[i] = from_f32<TY>(acc[rb][0][r]);
-          yr[32 + i] = from_f32<TY>(acc[rb][1][r]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int t = 0; t < 2; ++t) {
+          TY *yr = reinterpret_cast<TY *>(ys + i * YROW) + 4 * h;
 #pragma unroll
-        for (int ps = 0; ps < 32 / RPP; ++ps) {
-          const int rr = ps * RPP + rq;
-          const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
-          const long long mr = m0 + rb * 32 + rr;
-          if (mr < M)
-            *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(
-                y + mr * N + (size_t)n * 64) + pc * 16) = v;
+          for (int g = 0; g < 4; ++g) {
+            TY v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = from_f32<TY>(acc[rb][t][4 * g + e]);
+            if constexpr (sizeof(TY) == 2) {
+              unsigned long long pk;
+              __builtin_memcpy(&pk, v, 8);
+              *reinterpret_cast<unsigned long long *>(yr + 8 * g) = pk;
+            } else {
+              u32x4 pk;
+              __builtin_memcpy(&pk, v, 16);
+              *reinterpret_cast<u32x4 *>(yr + 8 * g) = pk;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int rr = ps * RPP + rq;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
+            const long long mr = m0 + rb * 32 + rr;
+            if (mr < M)
+              *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(
+                  y + mr * N + (size_t)n * 64 + t * 32) + pc * 16) = v;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
     }
   }
 }
@@ -183,7 +226,7 @@ struct SampleArgs {
   int img0, nimg;       // images of this chunk
   int H, W, Ho, Wo, Cout, CoutP, T;
   int kW, sH, sW, pH, pW, dH, dW;
-  int out_nhwc, relu, points;
+  int out_nhwc, relu, points, ablate;
 };
 
 // one 16-byte piece of a corner row, weight w, into fp32 accumulators
@@ -315,6 +358,12 @@ __global__ __launch_bounds__(SAMPLE_WAVES * 64) void cts_sample_kernel(SampleArg
       for (int tt = 0; tt < nt; ++tt) {
         const uint4 cx = *reinterpret_cast<const uint4 *>(s_off[wid][pj][tt]);
         const float4 w = *reinterpret_cast<const float4 *>(s_w[wid][pj][tt]);
+#ifdef GANET_ABLATE  // bit3: no gather (weights and coordinates still formed)
+        if (a.ablate & 8) {
+          acc[0] = acc[0] + f32x2{w.x + w.y, w.z + w.w} * __uint_as_float(cx.x ^ cx.y ^ cx.z ^ cx.w);
+          continue;
+        }
+#endif
         const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.x + lane_off, 0, 0);
         const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.y + lane_off, 0, 0);
         const u32x4 v3 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.z + lane_off, 0, 0);
@@ -369,30 +418,30 @@ __global__ __launch_bounds__(SAMPLE_WAVES * 64) void cts_sample_kernel(SampleArg
 
 template <typename TA, typename TY, int RB>
 void launch_gemm_rb(int kh, const void *x, const void *wq, void *y, long long M, int Cp,
-                    int N, hipStream_t s) {
+                    int N, int ablate, hipStream_t s) {
   constexpr int KBIG = sizeof(TA) == 4 ? 128 : 256;
-  constexpr int ROWS = GEMM_ROWS * RB;
+  constexpr int ROWS = GEMM_WAVES * 32 * RB;
   dim3 grid((unsigned)((M + ROWS - 1) / ROWS));
   dim3 block(GEMM_WAVES * 64);
   const TA *xx = static_cast<const TA *>(x);
   const TA *ww = static_cast<const TA *>(wq);
   TY *yy = static_cast<TY *>(y);
   if (kh == KBIG)
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, ablate);
   else if (kh == KBIG / 2)
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 2, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 2, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, ablate);
   else
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 4, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 4, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, ablate);
 }
 
 template <typename TA, typename TY>
 void launch_gemm(int kh, const void *x, const void *wq, void *y, long long M, int Cp,
-                 int N, hipStream_t s) {
+                 int N, int ablate, hipStream_t s) {
   // two row blocks per wavefront once that still leaves a workgroup for most CUs
-  if (M >= 160ll * GEMM_ROWS * 2)
-    launch_gemm_rb<TA, TY, 2>(kh, x, wq, y, M, Cp, N, s);
+  if (M >= 192ll * GEMM_WAVES * 64)
+    launch_gemm_rb<TA, TY, 2>(kh, x, wq, y, M, Cp, N, ablate, s);
   else
-    launch_gemm_rb<TA, TY, 1>(kh, x, wq, y, M, Cp, N, s);
+    launch_gemm_rb<TA, TY, 1>(kh, x, wq, y, M, Cp, N, ablate, s);
 }
 
 template <typename TY, typename TO>
@@ -426,7 +475,8 @@ bool cts_applicable(const ganet_dcn_params *p, int Cp, int CoutP) {
 int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta) {
   const size_t es = ta == GANET_F32 ? 4 : 2;
   const size_t per_img = (size_t)p->H * p->W * p->kH * p->kW * CoutP * es;
-  const size_t budget = 144ull << 20;
+  size_t budget = 144ull << 20;
+  if (const char *e = getenv("GANET_CTS_BUDGET_MB")) budget = (size_t)atoi(e) << 20;
   size_t nmax = budget / (per_img ? per_img : 1);
   if (nmax < 1) nmax = 1;
   if (nmax > (size_t)p->B) nmax = p->B;
@@ -458,11 +508,11 @@ int cts_forward(const void *xh, const float *offset, const float *mask, const vo
     const unsigned char *xc =
         static_cast<const unsigned char *>(xh) + (size_t)img0 * p->H * p->W * Cp * es;
     if (ta == GANET_F32)
-      launch_gemm<float, float>(kc, xc, wq, ybuf, M, Cp, N, s);
+      launch_gemm<float, float>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
     else if (ta == GANET_BF16)
-      launch_gemm<bf16_t, bf16_t>(kc, xc, wq, ybuf, M, Cp, N, s);
+      launch_gemm<bf16_t, bf16_t>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
     else
-      launch_gemm<f16_t, f16_t>(kc, xc, wq, ybuf, M, Cp, N, s);
+      launch_gemm<f16_t, f16_t>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
 
     SampleArgs a;
@@ -490,6 +540,7 @@ int cts_forward(const void *xh, const float *offset, const float *mask, const vo
     a.out_nhwc = p->out_layout == GANET_NHWC;
     a.relu = p->fuse_relu;
     a.points = p->offset_is_points;
+    a.ablate = p->debug;
     if (ta == GANET_F32)
       launch_sample<float, float>(a, s);
     else if (ta == GANET_BF16 && p->dtype == GANET_F32)

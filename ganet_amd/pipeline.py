@@ -53,6 +53,8 @@ class HotPath(object):
                 raise ValueError("unsupported LFA configuration")
             self.packed = torch.empty(nb, dtype=torch.uint8, device=self.device)
             self.ws_bytes = self.L.ganet_deform_conv_workspace_bytes(ctypes.byref(p))
+            # 1 = fused sample-then-contract kernel, 2 = contract-then-sample pair
+            self.lfa_algorithm = self.L.ganet_deform_conv_algorithm(ctypes.byref(p))
             self.ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8,
                                   device=self.device)
             self.feature = torch.empty(

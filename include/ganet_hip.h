@@ -101,9 +101,15 @@ typedef struct {
 int ganet_dcn_out_size(int in, int pad, int dilation, int k, int stride);
 
 /* Bytes of device scratch `ganet_deform_conv_forward` needs for `p`
- * (channel-last copy of x when x_layout is NCHW, repacked weights).
+ * (channel-last copy of x when x_layout is NCHW, repacked weights, the
+ * per-tap products of the contract-then-sample algorithm).
  * Returns 0 for invalid parameters. */
 size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p);
+
+/* Which algorithm ganet_deform_conv_forward runs for `p`: 1 or 2 as in
+ * ganet_dcn_params.algo (0 for invalid parameters).  No counterpart in the
+ * reference; for logs and benchmarks. */
+int ganet_deform_conv_algorithm(const ganet_dcn_params *p);
 
 /* Weight pre-packing (no counterpart in the reference, which hands the raw
  * [Cout,Cin,kH,kW] tensor to cuBLAS on every call, deform_conv_cuda.cpp:228-236):

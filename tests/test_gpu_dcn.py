@@ -132,6 +132,20 @@ def test_cts_with_mask_bias_relu_and_points():
         assert rel_err(gotp, ref) <= TOL_F32
 
 
+def test_cts_batch_large_enough_for_two_row_blocks_and_chunks():
+    """B*H*W >= 98304 rows: the GEMM runs two row blocks per wavefront; B = 40 images of
+    the LFA shape also spans two Y chunks (36 images fit the cache budget)."""
+    B, Cin, H, W, Cout, K = 40, 256, 40, 100, 64, 7
+    x, off, w, pts = synth.lfa_inputs(B, Cin, H, W, K, Cout=Cout, seed=21)
+    xr = torch.from_numpy(x).bfloat16().float().numpy()
+    wr = torch.from_numpy(w).bfloat16().float().numpy()
+    ref = O.deform_conv_forward(xr, off, wr, (1, 1), (0, 3), (1, 1), nthreads=16)
+    for algo in (0, 1, 2):
+        got = run_gpu(x, off, w, (1, 1), (0, 3), (1, 1), dtype=torch.bfloat16,
+                      channels_last=True, algo=algo)
+        assert rel_err(got, ref) <= TOL_16
+
+
 def test_fp32_storage_bf16_mfma():
     case = GENERIC[0]
     x, off, w = make(*case)
