@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--algo", type=int, default=0,
                     help="LFA algorithm: 0 auto, 1 sample-then-contract, 2 contract-then-sample")
     ap.add_argument("--pts", default="synthetic", choices=["synthetic", "zero"])
+    ap.add_argument("--device-pack", action="store_true",
+                    help="pack in device memory and copy D2H (default: the pack kernel "
+                         "writes the pinned host block directly)")
     ap.add_argument("--overlap-copy", action="store_true",
                     help="copy the lane lists D2H on a second stream")
     args = ap.parse_args()
@@ -190,7 +193,7 @@ def main():
                  thr=cfg["thr"], root_thr=cfg["root_thr"], cluster_thr=T, by_center_thr=T,
                  max_kpts=min(H * W, 4096 if cfg["lanes"] > 4 else 1024),
                  max_centers=256, overlap_copy=args.overlap_copy,
-                 ablate=args.ablate, algo=args.algo)
+                 ablate=args.ablate, algo=args.algo, pack_to_host=not args.device_pack)
     if args.pts == "zero":
         d["pts"].zero_()
     hp.set_weight(d["w"])

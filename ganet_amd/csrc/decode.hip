@@ -4,7 +4,8 @@
 //   GANetHeadFast.ktdet_decode_fast  mmdet/models/dense_heads/ganet_head.py:203-238
 //   group_points_fast                tools/ganet/post_process.py:141-194
 //
-// Two kernels:
+// Kernels (images up to 8192 pixels skip the first: the group kernel forms the bitmap
+// in LDS itself):
 //   decode_mask_kernel   grid (ceil(HW/256), B): 1x3 NMS + threshold, one pixel per
 //                        lane, one 64-pixel word of the keypoint bitmap per wavefront
 //                        ballot.  Reads the heat plane once, coalesced.
@@ -35,6 +36,7 @@ constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kMaxCenters = GANET_DECODE_MAX_CENTERS;  // LDS-resident centre list
 constexpr int kLdsGid = 8192;  // keypoint group ids kept in LDS (no-centre mode)
+constexpr int kFusedMaskWords = 128;  // images up to 8192 pixels: bitmap formed in LDS
 
 // heat * (max_pool2d(heat,(1,3),1,(0,1)) == heat)   ganet_head.py:205-208.
 // ATen's pool starts at -inf and takes v when (v > max) || isnan(v).
@@ -104,7 +106,8 @@ __device__ __forceinline__ int wave_min(int v) {
 
 struct DecodeArgs {
   const float *heat, *offset, *error;
-  const unsigned long long *kmask;
+  const unsigned long long *kmask;   // nullptr: the group kernel forms the bitmap itself
+  float kpt_thr;
   int H, W, nwords;
   float root_thr;
   double cluster_thr, by_center_thr;
@@ -120,6 +123,8 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
   __shared__ int smem[6 * kMaxCenters];
   __shared__ int wave_sums[kWavesPerBlock];
   __shared__ int s_nc, s_ng;
+  __shared__ unsigned long long s_mask[DECODE ? kFusedMaskWords : 1];
+  __shared__ __attribute__((aligned(16))) float s_heat[DECODE ? kFusedMaskWords * 64 : 1];
 
   unsigned int *ckey_raw = reinterpret_cast<unsigned int *>(smem);  // unsorted keys
   unsigned int *ckey = ckey_raw + kMaxCenters;                      // x-major keys
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
   const float *off_y = off_x + HW;
   const float *err_x = a.error + (size_t)b * 2 * HW;
   const float *err_y = err_x + HW;
-  const unsigned long long *kmask = a.kmask + (size_t)b * a.nwords;
+  const unsigned long long *kmask = a.kmask ? a.kmask + (size_t)b * a.nwords : nullptr;
 
   int32_t *o_counts = a.out.counts + (size_t)b * GANET_DECODE_COUNT_STRIDE;
   int32_t *o_cxy = a.out.centers_xy + (size_t)b * a.max_centers * 2;
@@ -156,6 +161,85 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
 
   int nk = 0, nc_found = 0, nk_st = 0, nc = 0, overflow = 0;
   if constexpr (DECODE) {
+  // ---- 0. small images: NMS + threshold here instead of in decode_mask_kernel
+  //         (one launch less).  The heat plane is staged in LDS with all loads in
+  //         flight at once; the bitmap never leaves LDS. --------------------------
+  const bool fused_mask = kmask == nullptr;
+  if (fused_mask) {
+    const float *hb = a.heat + (size_t)b * HW;
+    if ((HW & 3) == 0) {
+      // 16-byte loads, 8 per thread in flight (8192 pixels = 2048 float4)
+      const float4 *hb4 = reinterpret_cast<const float4 *>(hb);
+      float4 *sh4 = reinterpret_cast<float4 *>(s_heat);
+      const int n4 = (int)(HW >> 2);
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int q = tid + k * kBlock;
+        v[k] = hb4[q < n4 ? q : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int q = tid + k * kBlock;
+        if (q < n4) sh4[q] = v[k];
+      }
+    } else {
+      for (int p = tid; p < (int)HW; p += kBlock) s_heat[p] = hb[p];
+    }
+    __syncthreads();
+    for (int p0 = 0; p0 < (int)HW; p0 += kBlock) {
+      const int idx = p0 + tid;
+      bool is_kpt = false;
+      if (idx < (int)HW) {
+        const int y = idx / W;
+        const int x = idx - y * W;
+        is_kpt = heat_nms(s_heat + y * W, W, x) > a.kpt_thr;
+      }
+      const unsigned long long m = __ballot(is_kpt);
+      if (lane == 0 && (idx >> 6) < a.nwords) s_mask[idx >> 6] = m;
+    }
+    __syncthreads();
+  }
+  if (fused_mask) {
+    // ---- 1a. small images: ordered compaction of the pixel indices into LDS (the
+    //          heat copy is dead by now), then one keypoint per thread with its four
+    //          gathers in flight together - two memory round trips per image instead
+    //          of two per set bit. -------------------------------------------------
+    int *s_kidx = reinterpret_cast<int *>(s_heat);
+    for (int w0 = 0; w0 < a.nwords; w0 += kBlock) {
+      const int w = w0 + tid;
+      unsigned long long bits = (w < a.nwords) ? s_mask[w] : 0ull;
+      int total;
+      int pos = nk + block_excl_scan(__popcll(bits), wave_sums, &total);
+      nk += total;
+      while (bits) {
+        const int bit = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        s_kidx[pos++] = w * 64 + bit;   // pos < HW <= capacity of s_heat
+      }
+    }
+    __syncthreads();
+    for (int pos = tid; pos < nk; pos += kBlock) {
+      const int idx = s_kidx[pos];
+      const int y = idx / W, x = idx - y * W;
+      const float oy = off_y[idx], ox = off_x[idx], ex = err_x[idx], ey = err_y[idx];
+      if (pos < a.max_kpts) {
+        const float fx = (float)x, fy = (float)y;
+        o_kxy[2 * pos] = x;
+        o_kxy[2 * pos + 1] = y;
+        o_root[2 * pos] = fx + ox;      // ganet_head.py:229
+        o_root[2 * pos + 1] = fy + oy;
+        o_align[2 * pos] = fx + ex;     // ganet_head.py:230
+        o_align[2 * pos + 1] = fy + ey;
+        o_kgid[pos] = -1;
+      }
+      if (oy < a.root_thr) {            // centre (ganet_head.py:213-216)
+        const int slot = atomicAdd(&s_nc, 1);
+        if (slot < kMaxCenters)
+          ckey_raw[slot] = ((unsigned int)x << 16) | (unsigned int)y;
+      }
+    }
+  } else
   // ---- 1. ordered compaction of keypoints (row-major) ---------------------
   for (int w0 = 0; w0 < a.nwords; w0 += kBlock) {
     const int w = w0 + tid;
@@ -473,16 +557,20 @@ extern "C" int ganet_decode_batch(const float *heat, const float *offset,
   const int nwords = (HW + 63) / 64;
   unsigned long long *kmask = static_cast<unsigned long long *>(workspace);
 
-  dim3 g1((HW + kBlock - 1) / kBlock, p->B);
-  hipLaunchKernelGGL(decode_mask_kernel, g1, dim3(kBlock), 0, s, heat, HW,
-                     p->W, p->kpt_thr, kmask, nwords);
-  if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+  const bool fused_mask = nwords <= kFusedMaskWords;
+  if (!fused_mask) {
+    dim3 g1((HW + kBlock - 1) / kBlock, p->B);
+    hipLaunchKernelGGL(decode_mask_kernel, g1, dim3(kBlock), 0, s, heat, HW,
+                       p->W, p->kpt_thr, kmask, nwords);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+  }
 
   DecodeArgs a;
   a.heat = heat;
   a.offset = offset;
   a.error = error;
-  a.kmask = kmask;
+  a.kmask = fused_mask ? nullptr : kmask;
+  a.kpt_thr = p->kpt_thr;
   a.H = p->H;
   a.W = p->W;
   a.nwords = nwords;

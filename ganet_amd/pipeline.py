@@ -27,7 +27,7 @@ class HotPath(object):
                  by_center_thr=5.0, max_kpts=1024, max_centers=128,
                  channels_last=True, mfma_bf16=False, fuse_relu=True,
                  offset_is_points=True, expect_kpts=192, expect_centers=16,
-                 overlap_copy=False, ablate=0, algo=0):
+                 overlap_copy=False, ablate=0, algo=0, pack_to_host=True):
         self.L = _lib.lib()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.B, self.H, self.W, self.K = B, H, W, K
@@ -85,6 +85,7 @@ class HotPath(object):
             self.dws = torch.empty(max(self.dws_bytes, 256), dtype=torch.uint8,
                                    device=self.device)
             self.overlap_copy = overlap_copy
+            self.pack_to_host = pack_to_host and not overlap_copy
             self.copy_stream = (torch.cuda.Stream(device=self.device) if overlap_copy
                                 else None)
         self.params = dict(thr=thr, root_thr=root_thr, cluster_thr=cluster_thr,
@@ -128,6 +129,18 @@ class HotPath(object):
             ctypes.byref(self.dp), ctypes.byref(slot["bufs"].out),
             self.dws.data_ptr(), self.dws_bytes, cur_stream.cuda_stream)
         _lib.check(rc, "ganet_decode_batch")
+        if copy_to_host and self.pack_to_host:
+            # the pack kernel writes the dense record stream straight into the pinned
+            # host block (it only ever writes `packed`): no copy engine, no extra launch
+            rc = self.L.ganet_decode_pack(
+                ctypes.byref(self.dp), ctypes.byref(slot["bufs"].out),
+                slot["host"].data_ptr(), slot["host"].numel(), cur_stream.cuda_stream)
+            _lib.check(rc, "ganet_decode_pack")
+            slot["direct"] = True
+            self.last = slot
+            self.cur ^= 1
+            return
+        slot["direct"] = False
         slot["bufs"].pack(self.L, self.dp, cur_stream.cuda_stream)
         if copy_to_host:
             n = slot["bufs"].budget
@@ -154,7 +167,7 @@ class HotPath(object):
         slot = self.last
         bufs, host = slot["bufs"], slot["host"].numpy()
         total = bufs.header_words + int(host[6])
-        if total > bufs.budget:   # more was found than the async budget covered
+        if not slot.get("direct") and total > bufs.budget:   # beyond the async budget
             slot["host"][bufs.budget:total].copy_(bufs.packed[bufs.budget:total])
         header = host[:bufs.header_words].reshape(self.B, _lib.DECODE_COUNT_STRIDE)
         return DecodeResult(header.copy(), host[bufs.header_words:total].copy(),
