@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "fp32"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
-    ap.add_argument("--cpu-images", type=int, default=32)
+    ap.add_argument("--cpu-images", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)

@@ -61,7 +61,8 @@ int ganet_abi_version(void);
  * It is called from DeformConvFunction.forward (mmdet/ops/dcn/deform_conv.py:52-57).
  *
  * There is no im2col buffer and no im2col_step chunking: sampling and the
- * contraction are one fused kernel.
+ * contraction are one fused kernel, or (16-bit arithmetic, Cout < Cin) the
+ * commuted pair "per-tap GEMM, then sampling" - see `algo` below.
  * ---------------------------------------------------------------------- */
 typedef struct {
   int32_t B, Cin, H, W, Cout;
@@ -113,7 +114,7 @@ int ganet_deform_conv_algorithm(const ganet_dcn_params *p);
 
 /* Weight pre-packing (no counterpart in the reference, which hands the raw
  * [Cout,Cin,kH,kW] tensor to cuBLAS on every call, deform_conv_cuda.cpp:228-236):
- * the fused kernel reads weights as [tap][Cout][Cin] in its arithmetic dtype.
+ * the kernels read weights as [tap][Cout][Cin] in their arithmetic dtype.
  * ganet_deform_conv_forward packs into its workspace on every call unless
  * p->weight_is_packed is set and `weight` points at a buffer filled here. */
 size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p);
