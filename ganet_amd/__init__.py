@@ -5,6 +5,9 @@
   ganet_amd.decode        ktdet_decode_fast, decode_batch (mirror of
                           GANetHeadFast.ktdet_decode_fast)
   ganet_amd.post_process  PostProcessor (mirror of tools/ganet/post_process.py)
+  ganet_amd.formats       adjust_result, tusimple_convert_formal, out_result (mirror of
+                          the per-image formatting in tools/ganet/{tusimple,culane}/
+                          test_dataset.py and tools/ganet/common.py)
   ganet_amd.lfa           the LFA tail: offsets -> DeformConv1D -> ReLU, fused
   ganet_amd.synth         seeded synthetic inputs of the hot path's shapes
 
@@ -14,7 +17,7 @@ using an operator without the built library, or on CPU tensors, raises.
 """
 from . import _lib  # noqa: F401
 
-__all__ = ["dcn", "decode", "post_process", "lfa", "synth", "library_path"]
+__all__ = ["dcn", "decode", "post_process", "formats", "lfa", "synth", "library_path"]
 
 
 def library_path():

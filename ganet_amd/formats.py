@@ -1,0 +1,149 @@
+"""Host-side mirror of the steps between PostProcessor and the result files
+(SURVEY.md 8 f2): the per-image Python the reference runs after grouping.
+
+    adjust_result(lanes, centers, crop_bbox, img_shape, points_thr)
+        tools/ganet/tusimple/test_dataset.py:49-84 == tools/ganet/culane/test_dataset.py:79-113
+        heat-map-scaled points -> original image pixels: `int(v * ratio + offset)`
+        (truncation towards zero), lanes with `len(pts) > points_thr` kept.
+    get_line_intersection / tusimple_convert_formal     tools/ganet/common.py:118-147
+        x of every lane at the benchmark's h_samples rows, -2 where a lane has none.
+    tusimple_json_line                                   tusimple/test_dataset.py:203-213
+    out_result / culane_lines_text                       culane/test_dataset.py:138-148
+        `%.2f %.2f ...` one lane per line (CULane .lines.txt).
+
+Same names, argument meaning, return structures and in-place side effects as the
+reference (adjust_result overwrites the coordinates inside `lanes` / `centers`).
+The arithmetic is written on the same numpy / Python scalar types the reference
+handles, so numpy's promotion rules of the installed version apply identically
+(np.float32 * float is float64 before NEP 50 and float32 after it).
+
+`image_lanes` is the array form for the batched path: decoded image in, final integer
+lanes out, equal to PostProcessor -> adjust_result by construction and by test.
+"""
+import json
+
+import numpy as np
+
+
+def adjust_result(lanes, centers, crop_bbox, img_shape, points_thr):
+    h_img, w_img = img_shape[:2]
+    ratio_x = (crop_bbox[2] - crop_bbox[0]) / w_img
+    ratio_y = (crop_bbox[3] - crop_bbox[1]) / h_img
+    offset_x, offset_y = crop_bbox[:2]
+
+    results, virtual_centers, cluster_centers = [], [], []
+    if lanes is not None:
+        for lane in lanes:
+            pts, cts = [], []
+            for pt in lane['points']:
+                pt[0] = int(pt[0] * ratio_x + offset_x)
+                pt[1] = int(pt[1] * ratio_y + offset_y)
+                pts.append(tuple(pt))
+            for ct in lane['centers']:
+                ct[0] = int(ct[0] * ratio_x + offset_x)
+                ct[1] = int(ct[1] * ratio_y + offset_y)
+                cts.append(tuple(ct))
+            if len(pts) > points_thr:
+                results.append(pts)
+                virtual_centers.append(cts)
+    if centers is not None:
+        for center in centers:
+            c = center['center']
+            c[0] = int(c[0] * ratio_x + offset_x)
+            c[1] = int(c[1] * ratio_y + offset_y)
+            cluster_centers.append(tuple(c))
+    return results, virtual_centers, cluster_centers
+
+
+def _scalar_dtype(sample, ratio):
+    """dtype numpy gives `sample_scalar * python_float` in this installation."""
+    return np.asarray(sample * ratio).dtype
+
+
+def image_lanes(img, downscale, crop_bbox, img_shape, points_thr):
+    """PostProcessor.lane_post_process + adjust_result on the arrays of one decoded and
+    grouped image (DecodeResult.image(b)); returns (results, virtual_centers,
+    cluster_centers) as adjust_result does."""
+    h_img, w_img = img_shape[:2]
+    ratio = ((crop_bbox[2] - crop_bbox[0]) / w_img, (crop_bbox[3] - crop_bbox[1]) / h_img)
+    offset = (crop_bbox[0], crop_bbox[1])
+    gid = np.asarray(img["kpt_gid"])
+    align = np.asarray(img["align"], dtype=np.float32) * downscale        # float32
+    root = np.asarray(img["root"], dtype=np.float32).astype(np.float64) * downscale
+    results, virtual_centers = [], []
+
+    def to_int(v, axis_ratio, axis_offset):
+        # int(scalar * ratio + offset) for a whole column: product and sum in the dtype
+        # numpy gives the SCALAR expression in this installation, then truncation
+        # towards zero; int() errors on NaN / inf are kept
+        dt = _scalar_dtype(v.dtype.type(1), axis_ratio)
+        t = v.astype(dt) * dt.type(axis_ratio) + dt.type(axis_offset)
+        if np.isnan(t).any():
+            raise ValueError("cannot convert float NaN to integer")
+        if np.isinf(t).any():
+            raise OverflowError("cannot convert float infinity to integer")
+        return np.trunc(t).astype(np.int64)
+
+    n_groups = int(img["n_groups"])
+    if len(gid):
+        order = np.argsort(gid, kind="stable")
+        sg = gid[order]
+        starts = np.searchsorted(sg, np.arange(n_groups), side="left")
+        ends = np.searchsorted(sg, np.arange(n_groups), side="right")
+        px = to_int(align[:, 0], ratio[0], offset[0])
+        py = to_int(align[:, 1], ratio[1], offset[1])
+        cx = to_int(root[:, 0], ratio[0], offset[0])
+        cy = to_int(root[:, 1], ratio[1], offset[1])
+        for g in range(n_groups):
+            idx = order[starts[g]:ends[g]]
+            # lane_post_process keeps groups of more than one point, adjust_result
+            # those with more than points_thr
+            if len(idx) > 1 and len(idx) > points_thr:
+                results.append([(int(px[i]), int(py[i])) for i in idx])
+                virtual_centers.append([(int(cx[i]), int(cy[i])) for i in idx])
+    gc = np.asarray(img["group_center"], dtype=np.int64).reshape(-1, 2) * downscale
+    cluster_centers = []
+    if len(gc):
+        gx = to_int(gc[:, 0], ratio[0], offset[0])
+        gy = to_int(gc[:, 1], ratio[1], offset[1])
+        cluster_centers = [(int(a), int(b)) for a, b in zip(gx, gy)]
+    return results, virtual_centers, cluster_centers
+
+
+def get_line_intersection(y, line, im_width, reg_x=-2):
+    """x of the first segment of `line` whose y-range holds `y` (end points included,
+    horizontal segments skipped), rounded by `int(x + 0.49999)`; `reg_x` if none."""
+    for i in range(len(line) - 1):
+        (x0, y0), (x1, y1) = line[i], line[i + 1]
+        lo, hi = min(y0, y1), max(y0, y1)
+        if lo <= y <= hi and lo != hi:
+            k = (x1 - x0) / (y1 - y0)
+            return int(k * (y - y0) + x0 + 0.49999)
+    return reg_x
+
+
+def tusimple_convert_formal(lanes, h_samples, im_width, reg_x=-2):
+    return [[get_line_intersection(h, lane, im_width, reg_x) for h in h_samples]
+            for lane in lanes]
+
+
+def tusimple_json_line(result, h_samples, raw_file, im_width, run_time=20):
+    """One line of the TuSimple submission file (tusimple/test_dataset.py:203-213)."""
+    sample = dict(lanes=tusimple_convert_formal(result, h_samples, im_width),
+                  h_samples=h_samples, raw_file=raw_file, run_time=run_time)
+    return json.dumps(sample)
+
+
+def culane_lines_text(lanes):
+    """Text of a CULane `.lines.txt` file: one lane per line, `x y` pairs with two
+    decimals separated by single spaces."""
+    out = []
+    for lane in lanes:
+        out.append(" ".join("{:.2f} {:.2f}".format(p[0], p[1]) for p in lane) + "\n")
+    return "".join(out)
+
+
+def out_result(lanes, dst=None):
+    if dst is not None:
+        with open(dst, 'w') as f:
+            f.write(culane_lines_text(lanes))

@@ -113,3 +113,39 @@ def reference_group_points_fast(kpt_seeds, cpt_seeds, thr, by_center_thr):
     """Run the reference `group_points_fast` (post_process.py:141-194)."""
     _, pp = load_reference()
     return pp.group_points_fast(kpt_seeds, cpt_seeds, thr, by_center_thr)
+
+
+@functools.lru_cache(maxsize=1)
+def load_reference_formats():
+    """The reference's result formatting for the two datasets, executed where it lies:
+      tools/ganet/common.py                   get_line_intersection, tusimple_convert_formal
+      tools/ganet/tusimple/test_dataset.py    adjust_result            (:49-84)
+      tools/ganet/culane/test_dataset.py      adjust_result, out_result (:79-148)
+    common.py imports nothing and is loaded whole.  The two test_dataset.py scripts import
+    the whole training stack at module level, so only the named function definitions are
+    compiled out of the parsed file (no text of them is kept anywhere)."""
+    import ast
+
+    if not reference_available():
+        raise RuntimeError("reference tree not mounted at %s" % REFERENCE_ROOT)
+    sys.dont_write_bytecode = True
+    common = _load("_ganet_reference_common",
+                   os.path.join(REFERENCE_ROOT, "tools/ganet/common.py"))
+
+    def functions_of(path, names):
+        with open(path, "r") as f:
+            tree = ast.parse(f.read(), filename=path)
+        keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        ns = {}
+        exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+        return ns
+
+    tus = functions_of(os.path.join(REFERENCE_ROOT, "tools/ganet/tusimple/test_dataset.py"),
+                       ("adjust_result",))
+    cul = functions_of(os.path.join(REFERENCE_ROOT, "tools/ganet/culane/test_dataset.py"),
+                       ("adjust_result", "out_result"))
+    return dict(get_line_intersection=common.get_line_intersection,
+                tusimple_convert_formal=common.tusimple_convert_formal,
+                adjust_result_tusimple=tus["adjust_result"],
+                adjust_result_culane=cul["adjust_result"],
+                out_result=cul["out_result"])
