@@ -52,7 +52,7 @@ constexpr int TAP_BLOCK = 16;   // taps whose coordinates sit in LDS at a time
 template <typename TA, typename TY, int KH, int RB>
 __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
     const TA *__restrict__ x, const TA *__restrict__ wq, TY *__restrict__ y,
-    long long M, int Cp, int N, int ablate) {
+    long long M, int Cp, int N, int slices_per_block, int ablate) {
   constexpr int ES = sizeof(TA);
   constexpr int EPL = 16 / ES;
   constexpr int NQ = KH / (2 * EPL);          // 16-byte fragments per lane and K chunk
@@ -75,9 +75,14 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
     xrow[rb] = x + (r < M ? r : M - 1) * Cp + h * EPL;
   }
 
+  // blockIdx.y takes a range of the 64-column slices (small batches: more workgroups
+  // than row tiles alone would give; x is then re-read from L2 once per range)
   const int kchunks = Cp / KH;
-  const int nslices = N / 64;
+  const int slice0 = blockIdx.y * slices_per_block;
+  const int nslices = min(slices_per_block, N / 64 - slice0);
   const int total = nslices * kchunks;
+  wq += (size_t)slice0 * 64 * Cp;
+  y += (size_t)slice0 * 64;
 
   constexpr int BPIECES = 64 * (KH / EPL);
   constexpr int BPT = BPIECES / NT;           // 16-byte pieces per thread and slice
@@ -115,17 +120,31 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
         fa[rb][q] = __builtin_bit_cast(frag_t, ldg128(xrow[rb] + kc * KH + q * 2 * EPL));
   };
 
+#ifdef GANET_ABLATE
+  unsigned long long ts[40];
+  int nts = 0;
+  const bool stamp = (ablate & 32) && blockIdx.x == gridDim.x / 2 && tid == 0;
+#define GANET_STAMP() do { if (stamp && nts < 40) ts[nts++] = wall_clock64(); } while (0)
+#else
+#define GANET_STAMP() do {} while (0)
+#endif
+  GANET_STAMP();
   load_b(0, 0);
   load_a(0);
   store_b(0, 0);
   load_b(0, 1);
   store_b(0, 1);
+#ifdef GANET_ABLATE
+  if (ablate & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  GANET_STAMP();
 
   f32x16 acc[RB][2];
   for (int it = 0; it < total; ++it) {
     const int n = it / kchunks, kc = it - n * kchunks;
     const bool more = it + 1 < total;
     __syncthreads();  // slice `it` is in its buffer; the other buffer is free again
+    GANET_STAMP();
     if (more) load_b(it + 1, 0);
     if (kchunks > 1 && it > 0) load_a(kc);
     if (kc == 0) {
@@ -162,7 +181,9 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
         }
       }
     }
+    GANET_STAMP();
     if (more) store_b((it + 1) & 1, 1);
+    GANET_STAMP();
     if (kc == kchunks - 1) {
 #ifdef GANET_ABLATE  // bit2: keep only the first slice's stores
       if ((ablate & 4) && n > 0) {
@@ -213,7 +234,15 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+    GANET_STAMP();
   }
+#ifdef GANET_ABLATE
+  if (stamp) {
+    printf("gemm stamps (10 ns units, block %d):", (int)blockIdx.x);
+    for (int k = 1; k < nts; ++k) printf(" %d", (int)(ts[k] - ts[0]));
+    printf("\n");
+  }
+#endif
 }
 
 // ---- out = sum over taps of bilinear samples of Y -----------------------------------
@@ -421,17 +450,23 @@ void launch_gemm_rb(int kh, const void *x, const void *wq, void *y, long long M,
                     int N, int ablate, hipStream_t s) {
   constexpr int KBIG = sizeof(TA) == 4 ? 128 : 256;
   constexpr int ROWS = GEMM_WAVES * 32 * RB;
-  dim3 grid((unsigned)((M + ROWS - 1) / ROWS));
+  const unsigned gx = (unsigned)((M + ROWS - 1) / ROWS);
+  const int nslices = N / 64;
+  int ny = gx > 64 ? 1 : (int)((256 + gx - 1) / gx);
+  if (ny > nslices) ny = nslices;
+  const int per = (nslices + ny - 1) / ny;
+  ny = (nslices + per - 1) / per;
+  dim3 grid(gx, (unsigned)ny);
   dim3 block(GEMM_WAVES * 64);
   const TA *xx = static_cast<const TA *>(x);
   const TA *ww = static_cast<const TA *>(wq);
   TY *yy = static_cast<TY *>(y);
   if (kh == KBIG)
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, ablate);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per, ablate);
   else if (kh == KBIG / 2)
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 2, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, ablate);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 2, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per, ablate);
   else
-    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 4, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, ablate);
+    hipLaunchKernelGGL((cts_gemm_kernel<TA, TY, KBIG / 4, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per, ablate);
 }
 
 template <typename TA, typename TY>
