@@ -93,6 +93,36 @@ def deform_conv_forward(x, offset, weight, stride=(1, 1), padding=(0, 0),
     return out
 
 
+def deform_conv_backward(x, offset, weight, grad_out, stride=(1, 1), padding=(0, 0),
+                         dilation=(1, 1), groups=1, deformable_groups=1, mask=None):
+    """All gradients of the deformable convolution (NCHW float32); dict of arrays.
+    grad_mask / grad_bias only with a mask (DCNv2)."""
+    x, offset, weight, grad_out = _f32(x), _f32(offset), _f32(weight), _f32(grad_out)
+    mask = _f32(mask) if mask is not None else None
+    B, Cin, H, W = x.shape
+    Cout, _, kH, kW = weight.shape
+    gx = np.empty_like(x)
+    goff = np.empty_like(offset)
+    gw = np.empty_like(weight)
+    gm = np.empty_like(mask) if mask is not None else None
+    gb = np.empty(Cout, np.float32) if mask is not None else None
+    L = lib()
+    L.oracle_deform_conv_backward.restype = ctypes.c_int
+    L.oracle_deform_conv_backward.argtypes = [_f32p] * 10 + [ctypes.c_int] * 15
+    rc = L.oracle_deform_conv_backward(
+        _p(x, _f32p), _p(offset, _f32p), _p(mask, _f32p), _p(weight, _f32p),
+        _p(grad_out, _f32p), _p(gx, _f32p), _p(goff, _f32p), _p(gm, _f32p),
+        _p(gw, _f32p), _p(gb, _f32p), B, Cin, H, W, Cout, kH, kW,
+        stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+        groups, deformable_groups)
+    if rc != 0:
+        raise RuntimeError("oracle_deform_conv_backward failed: %d" % rc)
+    out = dict(grad_x=gx, grad_offset=goff, grad_weight=gw)
+    if mask is not None:
+        out.update(grad_mask=gm, grad_bias=gb)
+    return out
+
+
 def decode(heat, offset, error, thr, root_thr=1.0):
     """One image.  heat [H,W] (or [1,1,H,W]), offset/error [2,H,W].
     Returns centers int64 [Nc,2] (x,y; x-major), kpt_xy int32 [N,2],

@@ -184,6 +184,181 @@ int oracle_deform_conv_forward(const float *x, const float *offset,
 }
 
 /* ------------------------------------------------------------------------
+ * Backward of the deformable convolution (training):
+ *   deform_conv_backward_input_cuda / deform_conv_backward_parameters_cuda
+ *     (deform_conv_cuda.cpp:262-488) and modulated_deform_conv_cuda_backward
+ *   kernels deformable_col2im (deform_conv_cuda_kernel.cu:279-330),
+ *     deformable_col2im_coord (:363-427), their modulated forms (:636-755),
+ *   weights get_gradient_weight (:117-144), get_coordinate_weight (:146-188).
+ * Sums are taken in double (the checker should be the better value; the CUDA
+ * code's float atomics have no defined order anyway).
+ * ---------------------------------------------------------------------- */
+
+static double oracle_gradient_weight(float ah, float aw, int h, int w, int H, int W) {
+  if (ah <= -1 || ah >= H || aw <= -1 || aw >= W) return 0;
+  const int hl = (int)floorf(ah), wl = (int)floorf(aw);
+  const int hh = hl + 1, wh = wl + 1;
+  float weight = 0;
+  if (h == hl && w == wl) weight = (h + 1 - ah) * (w + 1 - aw);
+  if (h == hl && w == wh) weight = (h + 1 - ah) * (aw + 1 - w);
+  if (h == hh && w == wl) weight = (ah + 1 - h) * (w + 1 - aw);
+  if (h == hh && w == wh) weight = (ah + 1 - h) * (aw + 1 - w);
+  return weight;
+}
+
+static float oracle_coordinate_weight(float ah, float aw, int H, int W, const float *im,
+                                      int dir) {
+  if (ah <= -1 || ah >= H || aw <= -1 || aw >= W) return 0;
+  const int hl = (int)floorf(ah), wl = (int)floorf(aw);
+  const int hh = hl + 1, wh = wl + 1;
+  float weight = 0;
+  if (dir == 0) {
+    if (hl >= 0 && wl >= 0) weight += -1 * (wl + 1 - aw) * im[(size_t)hl * W + wl];
+    if (hl >= 0 && wh <= W - 1) weight += -1 * (aw - wl) * im[(size_t)hl * W + wh];
+    if (hh <= H - 1 && wl >= 0) weight += (wl + 1 - aw) * im[(size_t)hh * W + wl];
+    if (hh <= H - 1 && wh <= W - 1) weight += (aw - wl) * im[(size_t)hh * W + wh];
+  } else {
+    if (hl >= 0 && wl >= 0) weight += -1 * (hl + 1 - ah) * im[(size_t)hl * W + wl];
+    if (hl >= 0 && wh <= W - 1) weight += (hl + 1 - ah) * im[(size_t)hl * W + wh];
+    if (hh <= H - 1 && wl >= 0) weight += -1 * (ah - hl) * im[(size_t)hh * W + wl];
+    if (hh <= H - 1 && wh <= W - 1) weight += (ah - hl) * im[(size_t)hh * W + wh];
+  }
+  return weight;
+}
+
+/* All gradients of one call, NCHW float32.  mask NULL -> DCNv1 (grad_mask and grad_bias
+ * ignored).  Every output is fully overwritten.  Returns 0 or a negative code. */
+int oracle_deform_conv_backward(const float *x, const float *offset, const float *mask,
+                                const float *weight, const float *grad_out,
+                                float *grad_x, float *grad_offset, float *grad_mask,
+                                float *grad_weight, float *grad_bias, int B, int Cin,
+                                int H, int W, int Cout, int kH, int kW, int sH, int sW,
+                                int pH, int pW, int dH, int dW, int groups, int dgroups) {
+  if (kH <= 0 || kW <= 0 || sH <= 0 || sW <= 0 || dH <= 0 || dW <= 0) return -1;
+  if (groups <= 0 || dgroups <= 0 || Cin % groups || Cout % groups || Cin % dgroups)
+    return -1;
+  const int Hout = oracle_dcn_out_size(H, pH, dH, kH, sH);
+  const int Wout = oracle_dcn_out_size(W, pW, dW, kW, sW);
+  if (Hout < 1 || Wout < 1) return -2;
+  const int HWo = Hout * Wout, T = kH * kW;
+  const int Cig = Cin / groups, Cog = Cout / groups, cpg = Cin / dgroups;
+  const size_t nx = (size_t)B * Cin * H * W, nw = (size_t)Cout * Cig * T;
+  double *gx = (double *)calloc(nx, sizeof(double));
+  double *gw = (double *)calloc(nw, sizeof(double));
+  double *gcol = (double *)malloc(sizeof(double) * (size_t)Cin * T * HWo);
+  float *col = (float *)malloc(sizeof(float) * (size_t)Cin * T * HWo);
+  if (!gx || !gw || !gcol || !col) return -4;
+  for (int b = 0; b < B; ++b) {
+    const float *go = grad_out + (size_t)b * Cout * HWo;
+    const float *xb = x + (size_t)b * Cin * H * W;
+    const float *off = offset + (size_t)b * dgroups * 2 * T * HWo;
+    const float *msk = mask ? mask + (size_t)b * dgroups * T * HWo : NULL;
+    /* columns = weight^T * gradOutput  (deform_conv_cuda.cpp:336-345) */
+    for (int c = 0; c < Cin; ++c) {
+      const int g = c / Cig, cl = c - g * Cig;
+      for (int t = 0; t < T; ++t) {
+        double *row = gcol + ((size_t)c * T + t) * HWo;
+        for (int p = 0; p < HWo; ++p) row[p] = 0;
+        for (int o = g * Cog; o < (g + 1) * Cog; ++o) {
+          const double wv = weight[((size_t)o * Cig + cl) * T + t];
+          const float *gr = go + (size_t)o * HWo;
+          for (int p = 0; p < HWo; ++p) row[p] += wv * (double)gr[p];
+        }
+      }
+    }
+    /* the unmasked samples, for grad_weight and grad_mask */
+    oracle_im2col_one(xb, off, NULL, Cin, H, W, kH, kW, pH, pW, sH, sW, dH, dW, dgroups,
+                      Hout, Wout, col);
+    for (int c = 0; c < Cin; ++c) {
+      const int dg = c / cpg;
+      for (int t = 0; t < T; ++t) {
+        const int ki = t / kW, kj = t - ki * kW;
+        for (int ho = 0; ho < Hout; ++ho)
+          for (int wo = 0; wo < Wout; ++wo) {
+            const int p = ho * Wout + wo;
+            const size_t oh = ((size_t)(dg * 2 * T + 2 * t) * Hout + ho) * Wout + wo;
+            const size_t ow = ((size_t)(dg * 2 * T + 2 * t + 1) * Hout + ho) * Wout + wo;
+            const size_t om = ((size_t)(dg * T + t) * Hout + ho) * Wout + wo;
+            const float m = msk ? msk[om] : 1.f;
+            const double g = gcol[((size_t)c * T + t) * HWo + p];
+            const float ih = (float)(ho * sH - pH + ki * dH) + off[oh];
+            const float iw = (float)(wo * sW - pW + kj * dW) + off[ow];
+            /* col2im (:279-330): the up-to-four cells within distance 1 */
+            const int ch = (int)ih, cw = (int)iw;
+            for (int dy = -2; dy <= 2; ++dy)
+              for (int dx = -2; dx <= 2; ++dx) {
+                const int yy = ch + dy, xx = cw + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W && fabsf(ih - yy) < 1 &&
+                    fabsf(iw - xx) < 1)
+                  gx[((size_t)b * Cin + c) * H * W + (size_t)yy * W + xx] +=
+                      oracle_gradient_weight(ih, iw, yy, xx, H, W) * g * (double)m;
+              }
+          }
+      }
+    }
+    /* grad_offset / grad_mask: per (dg, t, p) sums over the group's channels */
+    for (int dg = 0; dg < dgroups; ++dg)
+      for (int t = 0; t < T; ++t) {
+        const int ki = t / kW, kj = t - ki * kW;
+        for (int ho = 0; ho < Hout; ++ho)
+          for (int wo = 0; wo < Wout; ++wo) {
+            const int p = ho * Wout + wo;
+            const size_t oh = ((size_t)(dg * 2 * T + 2 * t) * Hout + ho) * Wout + wo;
+            const size_t ow = ((size_t)(dg * 2 * T + 2 * t + 1) * Hout + ho) * Wout + wo;
+            const size_t om = ((size_t)(dg * T + t) * Hout + ho) * Wout + wo;
+            const float m = msk ? msk[om] : 1.f;
+            float ih = (float)(ho * sH - pH + ki * dH) + off[oh];
+            float iw = (float)(wo * sW - pW + kj * dW) + off[ow];
+            const int inside = !(ih <= -1 || iw <= -1 || ih >= H || iw >= W);
+            if (!inside) ih = iw = -2;
+            double vh = 0, vw = 0, vm = 0;
+            for (int c = dg * cpg; c < (dg + 1) * cpg; ++c) {
+              const float *im = xb + (size_t)c * H * W;
+              const double g = gcol[((size_t)c * T + t) * HWo + p];
+              vh += (double)oracle_coordinate_weight(ih, iw, H, W, im, 0) * g * (double)m;
+              vw += (double)oracle_coordinate_weight(ih, iw, H, W, im, 1) * g * (double)m;
+              if (inside) vm += g * (double)col[((size_t)c * T + t) * HWo + p];
+            }
+            grad_offset[(size_t)b * dgroups * 2 * T * HWo + oh] = (float)vh;
+            grad_offset[(size_t)b * dgroups * 2 * T * HWo + ow] = (float)vw;
+            if (mask && grad_mask) grad_mask[(size_t)b * dgroups * T * HWo + om] = (float)vm;
+          }
+      }
+    /* gradWeight += gradOutput * columns^T  (deform_conv_cuda.cpp:466-475) */
+    for (int o = 0; o < Cout; ++o) {
+      const int g = o / Cog;
+      const float *gr = go + (size_t)o * HWo;
+      for (int cl = 0; cl < Cig; ++cl) {
+        const int c = g * Cig + cl;
+        const int dg = c / cpg;
+        for (int t = 0; t < T; ++t) {
+          const float *cr = col + ((size_t)c * T + t) * HWo;
+          const float *mr = msk ? msk + (size_t)(dg * T + t) * HWo : NULL;
+          double acc = 0;
+          for (int p = 0; p < HWo; ++p)
+            acc += (double)gr[p] * (double)cr[p] * (mr ? (double)mr[p] : 1.0);
+          gw[((size_t)o * Cig + cl) * T + t] += acc;
+        }
+      }
+    }
+  }
+  for (size_t i = 0; i < nx; ++i) grad_x[i] = (float)gx[i];
+  for (size_t i = 0; i < nw; ++i) grad_weight[i] = (float)gw[i];
+  if (mask && grad_bias)
+    for (int o = 0; o < Cout; ++o) {
+      double acc = 0;
+      for (int b = 0; b < B; ++b)
+        for (int p = 0; p < HWo; ++p) acc += (double)grad_out[((size_t)b * Cout + o) * HWo + p];
+      grad_bias[o] = (float)acc;
+    }
+  free(gx);
+  free(gw);
+  free(gcol);
+  free(col);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------
  * Keypoint decode: GANetHeadFast.ktdet_decode_fast
  * (mmdet/models/dense_heads/ganet_head.py:203-238) for ONE image.
  * ---------------------------------------------------------------------- */

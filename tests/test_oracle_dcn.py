@@ -20,6 +20,18 @@ def torch_deform_conv(x, offset, weight, stride, padding, dilation, dg=1, mask=N
     x = torch.as_tensor(x, dtype=torch.float64)
     offset = torch.as_tensor(offset, dtype=torch.float64)
     weight = torch.as_tensor(weight, dtype=torch.float64)
+    if mask is not None:
+        mask = torch.as_tensor(mask, dtype=torch.float64)
+    if bias is not None:
+        bias = torch.as_tensor(bias, dtype=torch.float64)
+    return torch_deform_conv_t(x, offset, weight, stride, padding, dilation, dg, mask,
+                               bias).numpy()
+
+
+def torch_deform_conv_t(x, offset, weight, stride, padding, dilation, dg=1, mask=None,
+                        bias=None):
+    """The same on float64 tensors, differentiable (autograd is the checker of the
+    oracle's backward)."""
     B, C, H, W = x.shape
     Co, _, kH, kW = weight.shape
     Ho = (H + 2 * padding[0] - (dilation[0] * (kH - 1) + 1)) // stride[0] + 1
@@ -27,7 +39,7 @@ def torch_deform_conv(x, offset, weight, stride, padding, dilation, dg=1, mask=N
     ys = torch.arange(Ho, dtype=torch.float64).view(1, Ho, 1) * stride[0] - padding[0]
     xs = torch.arange(Wo, dtype=torch.float64).view(1, 1, Wo) * stride[1] - padding[1]
     cpg = C // dg
-    cols = torch.zeros(B, C, kH * kW, Ho, Wo, dtype=torch.float64)
+    cols = [[None] * (kH * kW) for _ in range(dg)]
     for g in range(dg):
         xg = x[:, g * cpg:(g + 1) * cpg]
         for i in range(kH):
@@ -45,7 +57,7 @@ def torch_deform_conv(x, offset, weight, stride, padding, dilation, dg=1, mask=N
                 lw = (wx - w0).double()
                 h0 = h0.long()
                 w0 = w0.long()
-                val = torch.zeros(B, cpg, Ho, Wo, dtype=torch.float64)
+                val = 0
                 for (dh, dw, wt) in [(0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw),
                                      (1, 0, lh * (1 - lw)), (1, 1, lh * lw)]:
                     hh, ww = h0 + dh, w0 + dw
@@ -55,15 +67,14 @@ def torch_deform_conv(x, offset, weight, stride, padding, dilation, dg=1, mask=N
                                      idx.expand(B, cpg, -1)).view(B, cpg, Ho, Wo)
                     val = val + (wt * ok).unsqueeze(1) * v
                 if mask is not None:
-                    val = val * torch.as_tensor(mask, dtype=torch.float64)[
-                        :, g * kH * kW + t].unsqueeze(1)
-                cols[:, g * cpg:(g + 1) * cpg, t] = val
-    out = torch.einsum("ockl,bcklhw->bohw",
-                       weight.view(Co, C, kH, kW),
-                       cols.view(B, C, kH, kW, Ho, Wo))
+                    val = val * mask[:, g * kH * kW + t].unsqueeze(1)
+                cols[g][t] = val
+    cols = torch.stack([torch.stack(cols[g], dim=2) for g in range(dg)], dim=1)
+    cols = cols.reshape(B, C, kH, kW, Ho, Wo)
+    out = torch.einsum("ockl,bcklhw->bohw", weight.view(Co, C, kH, kW), cols)
     if bias is not None:
-        out = out + torch.as_tensor(bias, dtype=torch.float64).view(1, -1, 1, 1)
-    return out.numpy()
+        out = out + bias.view(1, -1, 1, 1)
+    return out
 
 
 CASES = [
@@ -174,3 +185,38 @@ def test_lfa_synthetic_shape_runs_and_has_out_of_bounds_samples():
     assert got.shape == (1, 8, 20, 50) and np.isfinite(got).all()
     # base subtraction: offset = pts - [0,-p, 0,-p+1, ...]
     assert np.allclose(off[0, 1::2, 3, 4] + np.arange(-3, 4), pts[0, 1::2, 3, 4])
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("modulated", [False, True])
+def test_oracle_backward_vs_autograd(case, modulated):
+    """oracle_deform_conv_backward (the CUDA code's col2im / col2im_coord / weight GEMM
+    restated) against autograd through the float64 formulation above."""
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    rng = np.random.default_rng(123)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, kH, kW)) * 0.2).astype(np.float32)
+    Ho = O.dcn_out_size(H, pad[0], dil[0], kH, st[0])
+    Wo = O.dcn_out_size(W, pad[1], dil[1], kW, st[1])
+    off = (rng.standard_normal((B, dg * 2 * kH * kW, Ho, Wo)) * 1.7).astype(np.float32)
+    mask = rng.uniform(0.1, 1, (B, dg * kH * kW, Ho, Wo)).astype(np.float32) if modulated else None
+    go = rng.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)
+    got = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg, mask=mask)
+
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    toff = torch.tensor(off, dtype=torch.float64, requires_grad=True)
+    tw = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    tm = torch.tensor(mask, dtype=torch.float64, requires_grad=True) if modulated else None
+    tb = torch.zeros(Cout, dtype=torch.float64, requires_grad=True) if modulated else None
+    out = torch_deform_conv_t(tx, toff, tw, st, pad, dil, dg, tm, tb)
+    (out * torch.tensor(go, dtype=torch.float64)).sum().backward()
+
+    def close(a, b, what):
+        scale = max(np.abs(b).max(), 1e-30)
+        assert np.abs(a - b).max() / scale < 2e-5, what
+    close(got["grad_x"], tx.grad.numpy(), "grad_x")
+    close(got["grad_offset"], toff.grad.numpy(), "grad_offset")
+    close(got["grad_weight"], tw.grad.numpy(), "grad_weight")
+    if modulated:
+        close(got["grad_mask"], tm.grad.numpy(), "grad_mask")
+        close(got["grad_bias"], tb.grad.numpy(), "grad_bias")
