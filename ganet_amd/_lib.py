@@ -27,6 +27,7 @@ EXPORTS = (
     "ganet_deform_conv_packed_weight_bytes", "ganet_deform_conv_pack_weight",
     "ganet_decode_workspace_bytes", "ganet_decode_batch", "ganet_group_batch",
     "ganet_decode_pack", "ganet_deform_conv_algorithm",
+    "ganet_deform_conv_backward_workspace_bytes", "ganet_deform_conv_backward",
 )
 
 
@@ -86,6 +87,12 @@ def lib():
         L.ganet_deform_conv_forward.argtypes = [
             ctypes.c_void_p] * 6 + [ctypes.POINTER(DcnParams), ctypes.c_void_p,
                                     ctypes.c_size_t, ctypes.c_void_p]
+        L.ganet_deform_conv_backward_workspace_bytes.restype = ctypes.c_size_t
+        L.ganet_deform_conv_backward_workspace_bytes.argtypes = [ctypes.POINTER(DcnParams)]
+        L.ganet_deform_conv_backward.restype = ctypes.c_int
+        L.ganet_deform_conv_backward.argtypes = [
+            ctypes.c_void_p] * 10 + [ctypes.POINTER(DcnParams), ctypes.c_void_p,
+                                     ctypes.c_size_t, ctypes.c_void_p]
         L.ganet_deform_conv_packed_weight_bytes.restype = ctypes.c_size_t
         L.ganet_deform_conv_packed_weight_bytes.argtypes = [ctypes.POINTER(DcnParams)]
         L.ganet_deform_conv_pack_weight.restype = ctypes.c_int

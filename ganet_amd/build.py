@@ -19,7 +19,8 @@ COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17",
           "-Wall", "-Wno-unused-function"]
 # decode.hip must round like numpy / CPython: no fused multiply-add contraction.
 PER_FILE = {"decode.hip": ["-ffp-contract=off"]}
-SOURCES = ["api.hip", "decode.hip", "deform_conv.hip", "deform_conv_cts.hip"]
+SOURCES = ["api.hip", "decode.hip", "deform_conv.hip", "deform_conv_cts.hip",
+           "deform_conv_bwd.hip"]
 
 
 def _newer(a, b):

@@ -1,0 +1,567 @@
+// Deformable convolution backward for gfx950 (MI355X), float32 - the training side of
+// the drop-in.
+//
+// Replaces deform_conv_backward_input_cuda + deform_conv_backward_parameters_cuda
+// (mmdet/ops/dcn/src/cuda/deform_conv_cuda.cpp:262-488) and
+// modulated_deform_conv_cuda_backward (:571-700); kernel arithmetic:
+// deformable_col2im (deform_conv_cuda_kernel.cu:279-330), deformable_col2im_coord
+// (:363-427), get_gradient_weight / get_coordinate_weight (:117-188) and the modulated
+// forms (:636-755).
+//
+// The reference materialises grad_columns = W^T * grad_out ([Cin*T][pixels], ~1 GB at
+// the LFA's training shapes) and then runs col2im / col2im_coord over it.  Here the
+// columns never exist in memory:
+//
+//   dcn_bwd_input_kernel   a wavefront owns 32 output pixels.  Per (tap, 32-channel
+//       tile) it forms grad_col[32 px][32 c] on the matrix cores (fp32 32x32x2, K =
+//       Cout) and consumes the accumulators in place: 4 corner atomics into grad_x
+//       (channel-last, so one accumulator register is two 128-byte runs - the shape
+//       float atomics run at full rate on), 4 corner reads of x for the coordinate
+//       and mask gradients, which are reduced over channels in registers and over
+//       lanes by shuffles.
+//   dcn_bwd_weight_kernel  a workgroup owns one (tap, 32-channel tile) of grad_weight
+//       and a share of the pixels: it re-samples the columns (bilinear blend in
+//       registers) and contracts them with grad_out on the matrix cores
+//       (D[o][c] += go[p][o] * col[p][c], K = pixels), flushing once with atomics.
+//   dcn_bwd_bias_kernel    column sums of grad_out (DCNv2).
+//
+// Sums are fp32 and atomic, so results are order dependent at the last bits - as the
+// reference's own atomicAdd col2im is.
+
+#include "dcn_device.h"
+
+namespace ganet_dcn {
+
+namespace {
+
+struct BwdArgs {
+  const float *xh;      // [B*H*W][Cp] channel-last input
+  const float *offset;  // [B][dg*2T][Ho][Wo]
+  const float *mask;    // [B][dg*T][Ho][Wo] or nullptr
+  const float *wp;      // [T][Cout][Cp] packed weights
+  const float *go;      // [B*Ho*Wo][Cout] channel-last grad_out
+  float *gxh;           // [B*H*W][Cp], accumulated into
+  float *goff;          // like offset, zeroed before the launch, accumulated into
+  float *gmask;         // like mask or nullptr, zeroed, accumulated into
+  float *gwp;           // [T][Cout][Cp], zeroed, accumulated into
+  int B, H, W, Cp, Ho, Wo, Cout;
+  int kH, kW, sH, sW, pH, pW, dH, dW;
+  int dg, cpg;
+  long long P;          // B*Ho*Wo
+};
+
+// one sampling position: rows of xh of the four corners (-1: outside the map) and the
+// bilinear geometry, deform_conv_cuda_kernel.cu:84-115
+struct Sample {
+  int c1, c2, c3, c4;
+  float lh, lw, m;
+};
+
+__device__ __forceinline__ Sample make_sample(const BwdArgs &a, long long p, int t, int g) {
+  Sample s;
+  s.c1 = s.c2 = s.c3 = s.c4 = -1;
+  s.lh = s.lw = 0.f;
+  s.m = 0.f;
+  if (p >= a.P) return s;
+  const int HWo = a.Ho * a.Wo, T = a.kH * a.kW;
+  const int b = (int)(p / HWo);
+  const int hw = (int)(p - (long long)b * HWo);
+  const int ho = hw / a.Wo, wo = hw - ho * a.Wo;
+  const int ti = t / a.kW, tj = t - ti * a.kW;
+  const float *op = a.offset + ((size_t)(b * a.dg + g) * 2 * T + 2 * t) * HWo + hw;
+  const float h_im = (float)(ho * a.sH - a.pH + ti * a.dH) + ldg_f32(op);
+  const float w_im = (float)(wo * a.sW - a.pW + tj * a.dW) + ldg_f32(op + HWo);
+  s.m = a.mask ? ldg_f32(a.mask + ((size_t)(b * a.dg + g) * T + t) * HWo + hw) : 1.f;
+  if (h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W) {
+    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    s.lh = h_im - (float)h_low;
+    s.lw = w_im - (float)w_low;
+    const int base = (b * a.H + h_low) * a.W + w_low;
+    const bool hl = h_low >= 0, hh = h_high <= a.H - 1;
+    const bool wl = w_low >= 0, wh = w_high <= a.W - 1;
+    if (hl && wl) s.c1 = base;
+    if (hl && wh) s.c2 = base + 1;
+    if (hh && wl) s.c3 = base + a.W;
+    if (hh && wh) s.c4 = base + a.W + 1;
+  }
+  return s;
+}
+
+constexpr int TAB = 8;  // words per table entry
+
+__device__ __forceinline__ void put_sample(int *tab, int px, const Sample &s) {
+  int *e = tab + px * TAB;
+  e[0] = s.c1;
+  e[1] = s.c2;
+  e[2] = s.c3;
+  e[3] = s.c4;
+  e[4] = __float_as_int(s.lh);
+  e[5] = __float_as_int(s.lw);
+  e[6] = __float_as_int(s.m);
+  e[7] = 0;
+}
+__device__ __forceinline__ Sample get_sample(const int *tab, int px) {
+  const int4 u = *reinterpret_cast<const int4 *>(tab + px * TAB);
+  const int4 v = *reinterpret_cast<const int4 *>(tab + px * TAB + 4);
+  Sample s;
+  s.c1 = u.x;
+  s.c2 = u.y;
+  s.c3 = u.z;
+  s.c4 = u.w;
+  s.lh = __int_as_float(v.x);
+  s.lw = __int_as_float(v.y);
+  s.m = __int_as_float(v.z);
+  return s;
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float half_wave_sum(float v) {
+  // over the 32 lanes that share lane>>5
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int BW_WAVES = 4;
+
+// ---- grad_x, grad_offset, grad_mask ---------------------------------------------
+__global__ __launch_bounds__(BW_WAVES * 64) void dcn_bwd_input_kernel(BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) int s_tab[BW_WAVES][32 * TAB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const long long tile = (long long)blockIdx.x * BW_WAVES + wid;
+  const long long p0 = tile * 32;
+  if (p0 >= a.P) return;   // whole wave out (no workgroup barrier in this kernel)
+  int *tab = s_tab[wid];
+  const int T = a.kH * a.kW, HWo = a.Ho * a.Wo;
+  const long long pa = p0 + i;      // the pixel this lane feeds into the A operand
+
+  for (int ob = 0; ob < a.Cout; ob += 64) {
+    // A operand: grad_out[p][o], lane (i = pixel, h): o = ob + 2m + h
+    float ga[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      const int o = ob + 2 * m + h;
+      ga[m] = (pa < a.P && o < a.Cout) ? ldg_f32(a.go + pa * a.Cout + o) : 0.f;
+    }
+    for (int g = 0; g < a.dg; ++g) {
+      for (int t = 0; t < T; ++t) {
+        if (lane < 32) put_sample(tab, i, make_sample(a, p0 + i, t, g));
+        wave_sync_lds();
+        float dh[16], dw[16], dm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = dw[r] = dm[r] = 0.f;
+        const int ct0 = g * a.cpg / 32, ct1 = (g + 1) * a.cpg / 32;
+        for (int ct = ct0; ct < ct1; ++ct) {
+          const int c = ct * 32 + i;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          // grad_col[px][c] = sum_o go[px][o] * W[o][c][t]
+          const float *wrow = a.wp + ((size_t)t * a.Cout + ob + h) * a.Cp + c;
+#pragma unroll
+          for (int m = 0; m < 32; ++m) {
+            const float bv = (ob + 2 * m + h < a.Cout) ? ldg_f32(wrow + (size_t)2 * m * a.Cp) : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[m], bv, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const Sample s = get_sample(tab, px);
+            const float gc = acc[r];
+            const float gm = gc * s.m;
+            const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+            float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+            if (s.c1 >= 0) {
+              v1 = ldg_f32(a.xh + (size_t)s.c1 * a.Cp + c);
+              unsafeAtomicAdd(a.gxh + (size_t)s.c1 * a.Cp + c, hh * hw * gm);
+            }
+            if (s.c2 >= 0) {
+              v2 = ldg_f32(a.xh + (size_t)s.c2 * a.Cp + c);
+              unsafeAtomicAdd(a.gxh + (size_t)s.c2 * a.Cp + c, hh * s.lw * gm);
+            }
+            if (s.c3 >= 0) {
+              v3 = ldg_f32(a.xh + (size_t)s.c3 * a.Cp + c);
+              unsafeAtomicAdd(a.gxh + (size_t)s.c3 * a.Cp + c, s.lh * hw * gm);
+            }
+            if (s.c4 >= 0) {
+              v4 = ldg_f32(a.xh + (size_t)s.c4 * a.Cp + c);
+              unsafeAtomicAdd(a.gxh + (size_t)s.c4 * a.Cp + c, s.lh * s.lw * gm);
+            }
+            // get_coordinate_weight, deform_conv_cuda_kernel.cu:146-188
+            dh[r] += gm * (-hw * v1 - s.lw * v2 + hw * v3 + s.lw * v4);
+            dw[r] += gm * (-hh * v1 + hh * v2 - s.lh * v3 + s.lh * v4);
+            dm[r] += gc * (hh * hw * v1 + hh * s.lw * v2 + s.lh * hw * v3 + s.lh * s.lw * v4);
+          }
+        }
+        // channels of this group -> one value per (pixel, tap, direction)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sh = half_wave_sum(dh[r]);
+          const float sw = half_wave_sum(dw[r]);
+          const float sm = a.gmask ? half_wave_sum(dm[r]) : 0.f;
+          const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const long long p = p0 + px;
+          if (i == 0 && p < a.P) {
+            const int b = (int)(p / HWo);
+            const int hw_ = (int)(p - (long long)b * HWo);
+            float *q = a.goff + ((size_t)(b * a.dg + g) * 2 * T + 2 * t) * HWo + hw_;
+            unsafeAtomicAdd(q, sh);
+            unsafeAtomicAdd(q + HWo, sw);
+            if (a.gmask)
+              unsafeAtomicAdd(a.gmask + ((size_t)(b * a.dg + g) * T + t) * HWo + hw_, sm);
+          }
+        }
+        wave_sync_lds();  // the table is rewritten for the next tap
+      }
+    }
+  }
+}
+
+// ---- grad_weight -------------------------------------------------------------------
+// grid.x = T * (Cp / 32): one (tap, channel tile); grid.y: shares of the pixel tiles
+__global__ __launch_bounds__(BW_WAVES * 64) void dcn_bwd_weight_kernel(BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) int s_tab[BW_WAVES][32 * TAB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int nct = a.Cp / 32;
+  const int t = blockIdx.x / nct, ct = blockIdx.x - t * nct;
+  const int g = (ct * 32) / a.cpg;
+  const int c = ct * 32 + i;
+  int *tab = s_tab[wid];
+  const long long ntiles = (a.P + 31) / 32;
+
+  for (int ob = 0; ob < a.Cout; ob += 64) {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    for (long long tile = (long long)blockIdx.y * BW_WAVES + wid; tile < ntiles;
+         tile += (long long)gridDim.y * BW_WAVES) {
+      const long long p0 = tile * 32;
+      if (lane < 32) put_sample(tab, i, make_sample(a, p0 + i, t, g));
+      wave_sync_lds();
+#pragma unroll 4
+      for (int m = 0; m < 16; ++m) {
+        const int px = 2 * m + h;
+        const long long p = p0 + px;
+        const Sample s = get_sample(tab, px);
+        const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+        float col = 0.f;
+        if (s.c1 >= 0) col += hh * hw * ldg_f32(a.xh + (size_t)s.c1 * a.Cp + c);
+        if (s.c2 >= 0) col += hh * s.lw * ldg_f32(a.xh + (size_t)s.c2 * a.Cp + c);
+        if (s.c3 >= 0) col += s.lh * hw * ldg_f32(a.xh + (size_t)s.c3 * a.Cp + c);
+        if (s.c4 >= 0) col += s.lh * s.lw * ldg_f32(a.xh + (size_t)s.c4 * a.Cp + c);
+        col *= s.m;
+        float a0 = 0.f, a1 = 0.f;
+        if (p < a.P) {
+          if (ob + i < a.Cout) a0 = ldg_f32(a.go + p * a.Cout + ob + i);
+          if (ob + 32 + i < a.Cout) a1 = ldg_f32(a.go + p * a.Cout + ob + 32 + i);
+        }
+        // D[o][c] += go[p][o] * col[p][c], k = the pixel pair (2m, 2m+1)
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, col, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, col, acc1, 0, 0, 0);
+      }
+      wave_sync_lds();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (o < a.Cout) unsafeAtomicAdd(a.gwp + ((size_t)t * a.Cout + o) * a.Cp + c, acc0[r]);
+      if (o + 32 < a.Cout)
+        unsafeAtomicAdd(a.gwp + ((size_t)t * a.Cout + o + 32) * a.Cp + c, acc1[r]);
+    }
+  }
+}
+
+// grad_bias[o] += sum_p go[p][o]
+__global__ __launch_bounds__(256) void dcn_bwd_bias_kernel(const float *__restrict__ go,
+                                                           float *__restrict__ gb,
+                                                           long long P, int Cout) {
+  const int o0 = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  for (int o = o0; o < Cout; o += 64) {
+    float s = 0.f;
+    for (long long p = (long long)blockIdx.x * 4 + sub; p < P; p += (long long)gridDim.x * 4)
+      s += go[p * Cout + o];
+    unsafeAtomicAdd(gb + o, s);
+  }
+}
+
+// ---- layout helpers ------------------------------------------------------------------
+// src[B][C][HW] -> dst[B*HW][Cp] (zero padded channels)
+__global__ __launch_bounds__(256) void bwd_nchw_to_nhwc_kernel(const float *__restrict__ src,
+                                                               float *__restrict__ dst,
+                                                               int C, int HW, int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int cc = ty; cc < 64; cc += 4) {
+    float v = 0.f;
+    if (c0 + cc < C && p0 + tx < HW) v = src[((size_t)b * C + c0 + cc) * HW + p0 + tx];
+    tile[cc][tx] = v;
+  }
+  __syncthreads();
+  for (int pp = ty; pp < 64; pp += 4)
+    if (p0 + pp < HW && c0 + tx < Cp) dst[((size_t)b * HW + p0 + pp) * Cp + c0 + tx] = tile[tx][pp];
+}
+
+// dst[B][C][HW] += src[B*HW][Cp]
+__global__ __launch_bounds__(256) void bwd_add_nhwc_to_nchw_kernel(const float *__restrict__ src,
+                                                                   float *__restrict__ dst,
+                                                                   int C, int HW, int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int pp = ty; pp < 64; pp += 4) {
+    float v = 0.f;
+    if (p0 + pp < HW && c0 + tx < Cp) v = src[((size_t)b * HW + p0 + pp) * Cp + c0 + tx];
+    tile[pp][tx] = v;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4)
+    if (c0 + cc < C && p0 + tx < HW) dst[((size_t)b * C + c0 + cc) * HW + p0 + tx] += tile[tx][cc];
+}
+
+// src[N][C] -> dst[N][Cp] (zero padded); and dst[N][C] += src[N][Cp]
+__global__ __launch_bounds__(256) void bwd_pad_rows_kernel(const float *__restrict__ src,
+                                                           float *__restrict__ dst, long long n,
+                                                           int C, int Cp) {
+  const long long total = n * Cp;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
+       k += (long long)gridDim.x * 256) {
+    const long long r = k / Cp;
+    const int cc = (int)(k - r * Cp);
+    dst[k] = cc < C ? src[r * C + cc] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void bwd_add_rows_kernel(const float *__restrict__ src,
+                                                           float *__restrict__ dst, long long n,
+                                                           int C, int Cp) {
+  const long long total = n * C;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
+       k += (long long)gridDim.x * 256) {
+    const long long r = k / C;
+    const int cc = (int)(k - r * C);
+    dst[k] += src[r * Cp + cc];
+  }
+}
+
+// W[Cout][Cin][T] -> wp[T][Cout][Cp]; and gw[Cout][Cin][T] += gwp[T][Cout][Cp]
+__global__ __launch_bounds__(256) void bwd_pack_weight_kernel(const float *__restrict__ w,
+                                                              float *__restrict__ wp, int Cout,
+                                                              int Cin, int T, int Cp) {
+  const long long total = (long long)T * Cout * Cp;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
+       k += (long long)gridDim.x * 256) {
+    const int cc = (int)(k % Cp);
+    const int o = (int)((k / Cp) % Cout);
+    const int t = (int)(k / ((long long)Cp * Cout));
+    wp[k] = cc < Cin ? w[((size_t)o * Cin + cc) * T + t] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void bwd_unpack_add_weight_kernel(
+    const float *__restrict__ gwp, float *__restrict__ gw, int Cout, int Cin, int T, int Cp) {
+  const long long total = (long long)Cout * Cin * T;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
+       k += (long long)gridDim.x * 256) {
+    const int t = (int)(k % T);
+    const int cc = (int)((k / T) % Cin);
+    const int o = (int)(k / ((long long)T * Cin));
+    gw[k] += gwp[((size_t)t * Cout + o) * Cp + cc];
+  }
+}
+
+struct BwdPlan {
+  int Ho, Wo, T, Cp;
+  bool copy_x, copy_go;
+  size_t xh_bytes, gxh_bytes, go_bytes, wp_bytes, gwp_bytes;
+};
+
+int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
+  if (!p) return GANET_ERR_NULL;
+  if (p->B <= 0 || p->Cin <= 0 || p->H <= 0 || p->W <= 0 || p->Cout <= 0)
+    return GANET_ERR_BAD_SHAPE;
+  if (p->kH <= 0 || p->kW <= 0 || p->sH <= 0 || p->sW <= 0 || p->dH <= 0 || p->dW <= 0 ||
+      p->pH < 0 || p->pW < 0)
+    return GANET_ERR_BAD_SHAPE;
+  if (p->groups <= 0 || p->deformable_groups <= 0) return GANET_ERR_BAD_SHAPE;
+  if (p->Cin % p->groups || p->Cout % p->groups || p->Cin % p->deformable_groups)
+    return GANET_ERR_BAD_SHAPE;
+  if (p->dtype != GANET_F32) return GANET_ERR_UNSUPPORTED;   // training runs in float32
+  if (p->groups != 1) return GANET_ERR_UNSUPPORTED;
+  if (p->offset_is_points || p->fuse_relu || p->weight_is_packed) return GANET_ERR_UNSUPPORTED;
+  pl->Ho = ganet_dcn_out_size(p->H, p->pH, p->dH, p->kH, p->sH);
+  pl->Wo = ganet_dcn_out_size(p->W, p->pW, p->dW, p->kW, p->sW);
+  if (pl->Ho < 1 || pl->Wo < 1) return GANET_ERR_BAD_SHAPE;
+  pl->T = p->kH * p->kW;
+  const int dg = p->deformable_groups;
+  // channel tiles of 32 must not straddle deformable groups
+  if (dg > 1 && (p->Cin / dg) % 32) return GANET_ERR_UNSUPPORTED;
+  pl->Cp = (p->Cin + 31) / 32 * 32;
+  const size_t npix_in = (size_t)p->B * p->H * p->W;
+  const size_t npix_out = (size_t)p->B * pl->Ho * pl->Wo;
+  if (npix_in * pl->Cp >= 0x7fffffffull || npix_out >= 0x7fffffffull)
+    return GANET_ERR_UNSUPPORTED;  // 32-bit row indices in the sample table
+  pl->copy_x = p->x_layout != GANET_NHWC || pl->Cp != p->Cin;
+  pl->copy_go = p->out_layout != GANET_NHWC;
+  pl->xh_bytes = pl->copy_x ? ganet_align_up(npix_in * pl->Cp * 4, 256) : 0;
+  pl->gxh_bytes = pl->xh_bytes;
+  pl->go_bytes = pl->copy_go ? ganet_align_up(npix_out * p->Cout * 4, 256) : 0;
+  pl->wp_bytes = ganet_align_up((size_t)pl->T * p->Cout * pl->Cp * 4, 256);
+  pl->gwp_bytes = pl->wp_bytes;
+  return GANET_OK;
+}
+
+}  // namespace
+
+}  // namespace ganet_dcn
+
+using namespace ganet_dcn;
+
+extern "C" size_t ganet_deform_conv_backward_workspace_bytes(const ganet_dcn_params *p) {
+  BwdPlan pl;
+  if (make_bwd_plan(p, &pl) != GANET_OK) return 0;
+  return pl.xh_bytes + pl.gxh_bytes + pl.go_bytes + pl.wp_bytes + pl.gwp_bytes;
+}
+
+extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
+                                          const float *mask, const void *weight,
+                                          const void *grad_out, void *grad_x,
+                                          float *grad_offset, float *grad_mask,
+                                          void *grad_weight, void *grad_bias,
+                                          const ganet_dcn_params *p, void *workspace,
+                                          size_t workspace_bytes, ganet_stream_t stream) {
+  if (!x || !offset || !weight || !grad_out || !p || !workspace) return GANET_ERR_NULL;
+  const bool need_in = grad_x != nullptr || grad_offset != nullptr;
+  if (need_in && (!grad_x || !grad_offset)) return GANET_ERR_NULL;  // computed together
+  if (grad_mask && !mask) return GANET_ERR_NULL;
+  if (mask && need_in && !grad_mask) return GANET_ERR_NULL;
+  BwdPlan pl;
+  const int rc = make_bwd_plan(p, &pl);
+  if (rc != GANET_OK) return rc;
+  const size_t need = pl.xh_bytes + pl.gxh_bytes + pl.go_bytes + pl.wp_bytes + pl.gwp_bytes;
+  if (workspace_bytes < need) return GANET_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  float *xh = reinterpret_cast<float *>(ws);
+  float *gxh = reinterpret_cast<float *>(ws + pl.xh_bytes);
+  float *goh = reinterpret_cast<float *>(ws + pl.xh_bytes + pl.gxh_bytes);
+  float *wp = reinterpret_cast<float *>(ws + pl.xh_bytes + pl.gxh_bytes + pl.go_bytes);
+  float *gwp = reinterpret_cast<float *>(ws + pl.xh_bytes + pl.gxh_bytes + pl.go_bytes + pl.wp_bytes);
+
+  const int HW = p->H * p->W, HWo = pl.Ho * pl.Wo, T = pl.T;
+  const long long npix_in = (long long)p->B * HW, P = (long long)p->B * HWo;
+  const float *xf = static_cast<const float *>(x);
+  const float *gof = static_cast<const float *>(grad_out);
+  auto blocks_for = [](long long n) {
+    long long b = (n + 255) / 256;
+    return (unsigned)(b > 65535 ? 65535 : (b < 1 ? 1 : b));
+  };
+
+  // channel-last views of x and grad_out
+  if (pl.copy_x) {
+    if (p->x_layout == GANET_NHWC) {
+      hipLaunchKernelGGL(bwd_pad_rows_kernel, dim3(blocks_for(npix_in * pl.Cp)), dim3(256), 0, s,
+                         xf, xh, npix_in, p->Cin, pl.Cp);
+    } else {
+      dim3 grid((HW + 63) / 64, (pl.Cp + 63) / 64, p->B);
+      hipLaunchKernelGGL(bwd_nchw_to_nhwc_kernel, grid, dim3(256), 0, s, xf, xh, p->Cin, HW, pl.Cp);
+    }
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+  }
+  if (pl.copy_go) {
+    dim3 grid((HWo + 63) / 64, (p->Cout + 63) / 64, p->B);
+    hipLaunchKernelGGL(bwd_nchw_to_nhwc_kernel, grid, dim3(256), 0, s, gof, goh, p->Cout, HWo,
+                       p->Cout);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+  }
+
+  BwdArgs a;
+  a.xh = pl.copy_x ? xh : xf;
+  a.offset = offset;
+  a.mask = mask;
+  a.wp = wp;
+  a.go = pl.copy_go ? goh : gof;
+  a.gxh = pl.copy_x ? gxh : static_cast<float *>(grad_x);
+  a.goff = grad_offset;
+  a.gmask = grad_mask;
+  a.gwp = gwp;
+  a.B = p->B;
+  a.H = p->H;
+  a.W = p->W;
+  a.Cp = pl.Cp;
+  a.Ho = pl.Ho;
+  a.Wo = pl.Wo;
+  a.Cout = p->Cout;
+  a.kH = p->kH;
+  a.kW = p->kW;
+  a.sH = p->sH;
+  a.sW = p->sW;
+  a.pH = p->pH;
+  a.pW = p->pW;
+  a.dH = p->dH;
+  a.dW = p->dW;
+  a.dg = p->deformable_groups;
+  a.cpg = pl.Cp / p->deformable_groups;   // dg > 1 implies Cp == Cin
+  a.P = P;
+
+  if (need_in) {
+    hipLaunchKernelGGL(bwd_pack_weight_kernel, dim3(blocks_for((long long)T * p->Cout * pl.Cp)),
+                       dim3(256), 0, s, static_cast<const float *>(weight), wp, p->Cout, p->Cin,
+                       T, pl.Cp);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    if (pl.copy_x && hipMemsetAsync(gxh, 0, pl.gxh_bytes, s) != hipSuccess) return GANET_ERR_HIP;
+    const size_t off_elems = (size_t)p->B * a.dg * 2 * T * HWo;
+    if (hipMemsetAsync(grad_offset, 0, off_elems * 4, s) != hipSuccess) return GANET_ERR_HIP;
+    if (grad_mask && hipMemsetAsync(grad_mask, 0, off_elems * 2, s) != hipSuccess)
+      return GANET_ERR_HIP;
+    const long long tiles = (P + 31) / 32;
+    hipLaunchKernelGGL(dcn_bwd_input_kernel, dim3((unsigned)((tiles + BW_WAVES - 1) / BW_WAVES)),
+                       dim3(BW_WAVES * 64), 0, s, a);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    if (pl.copy_x) {
+      float *gx = static_cast<float *>(grad_x);
+      if (p->x_layout == GANET_NHWC) {
+        hipLaunchKernelGGL(bwd_add_rows_kernel, dim3(blocks_for(npix_in * p->Cin)), dim3(256), 0,
+                           s, gxh, gx, npix_in, p->Cin, pl.Cp);
+      } else {
+        dim3 grid((HW + 63) / 64, (pl.Cp + 63) / 64, p->B);
+        hipLaunchKernelGGL(bwd_add_nhwc_to_nchw_kernel, grid, dim3(256), 0, s, gxh, gx, p->Cin,
+                           HW, pl.Cp);
+      }
+      if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    }
+  }
+  if (grad_weight) {
+    if (hipMemsetAsync(gwp, 0, pl.gwp_bytes, s) != hipSuccess) return GANET_ERR_HIP;
+    const long long tiles = (P + 31) / 32;
+    long long split = (tiles + BW_WAVES * 8 - 1) / (BW_WAVES * 8);   // >= 8 tiles per wave
+    const long long want = 2048 / ((long long)T * (pl.Cp / 32)) + 1;
+    if (split > want) split = want;
+    if (split < 1) split = 1;
+    dim3 grid((unsigned)(T * (pl.Cp / 32)), (unsigned)split);
+    hipLaunchKernelGGL(dcn_bwd_weight_kernel, grid, dim3(BW_WAVES * 64), 0, s, a);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    hipLaunchKernelGGL(bwd_unpack_add_weight_kernel,
+                       dim3(blocks_for((long long)p->Cout * p->Cin * T)), dim3(256), 0, s, gwp,
+                       static_cast<float *>(grad_weight), p->Cout, p->Cin, T, pl.Cp);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+  }
+  if (grad_bias) {
+    long long nb = (P + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3((unsigned)nb), dim3(256), 0, s, a.go,
+                       static_cast<float *>(grad_bias), P, p->Cout);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+  }
+  return GANET_OK;
+}

@@ -157,6 +157,70 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
     return out
 
 
+def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
+                         padding=(0, 0), dilation=(1, 1), groups=1, deformable_groups=1,
+                         mask=None, need_input=True, need_weight=True, need_bias=False):
+    """Raw backward on the HIP library (float32).  Returns
+    (grad_input, grad_offset, grad_mask, grad_weight, grad_bias); entries that were not
+    asked for (or have no meaning without a mask) are None.  grad_input has the memory
+    format of `input`."""
+    if not grad_output.is_cuda or not input.is_cuda:
+        raise NotImplementedError
+    if input.dtype != torch.float32:
+        raise NotImplementedError(
+            "ganet_amd: deform_conv backward is built for float32 only (got %s)" % input.dtype)
+    L = _lib.lib()
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    nhwc = _is_channels_last(input)
+    if not nhwc:
+        input = input.contiguous()
+    weight = weight.contiguous().float()
+    offset = offset.contiguous().float()
+    if mask is not None:
+        mask = mask.contiguous().float()
+    go_nhwc = _is_channels_last(grad_output)
+    grad_output = grad_output.float()
+    if not go_nhwc:
+        grad_output = grad_output.contiguous()
+    B, Cin, H, W = input.shape
+    Cout, _, kH, kW = weight.shape
+    p = _lib.DcnParams()
+    p.B, p.Cin, p.H, p.W, p.Cout = B, Cin, H, W, Cout
+    p.kH, p.kW = kH, kW
+    p.sH, p.sW = stride
+    p.pH, p.pW = padding
+    p.dH, p.dW = dilation
+    p.groups, p.deformable_groups = groups, deformable_groups
+    p.dtype = _lib.GANET_F32
+    p.x_layout = _lib.GANET_NHWC if nhwc else _lib.GANET_NCHW
+    p.out_layout = _lib.GANET_NHWC if go_nhwc else _lib.GANET_NCHW
+    grad_input = grad_offset = grad_mask = grad_weight = grad_bias = None
+    if need_input:
+        grad_input = torch.zeros_like(input)       # keeps the memory format
+        grad_offset = torch.empty_like(offset)
+        if mask is not None:
+            grad_mask = torch.empty_like(mask)
+    if need_weight:
+        grad_weight = torch.zeros_like(weight)
+    if need_bias:
+        grad_bias = torch.zeros(Cout, dtype=torch.float32, device=input.device)
+
+    def ptr(t):
+        return t.data_ptr() if t is not None else None
+
+    with torch.cuda.device(input.device):
+        ws_bytes = L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(p))
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=input.device)
+        stream = torch.cuda.current_stream(input.device).cuda_stream
+        rc = L.ganet_deform_conv_backward(
+            input.data_ptr(), offset.data_ptr(), ptr(mask), weight.data_ptr(),
+            grad_output.data_ptr(), ptr(grad_input), ptr(grad_offset), ptr(grad_mask),
+            ptr(grad_weight), ptr(grad_bias), ctypes.byref(p), ws.data_ptr(),
+            max(ws_bytes, 256) if ws_bytes else 0, stream)
+    _lib.check(rc, "ganet_deform_conv_backward")
+    return grad_input, grad_offset, grad_mask, grad_weight, grad_bias
+
+
 class DeformConvFunction(Function):
 
     @staticmethod
@@ -197,8 +261,21 @@ class DeformConvFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        raise NotImplementedError(
-            'ganet_amd: deform_conv backward is not built (inference hot path only)')
+        # deform_conv.py:60-96
+        input, offset, weight = ctx.saved_tensors
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        cur_im2col_step = min(ctx.im2col_step, input.shape[0])
+        assert (input.shape[0] %
+                cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        need_input = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_weight = ctx.needs_input_grad[2]
+        grad_input, grad_offset, _, grad_weight, _ = deform_conv_backward(
+            input, offset, weight, grad_output, ctx.stride, ctx.padding, ctx.dilation,
+            ctx.groups, ctx.deformable_groups, need_input=need_input,
+            need_weight=need_weight)
+        return (grad_input, grad_offset, grad_weight, None, None, None, None,
+                None, None)
 
     @staticmethod
     def _output_size(input, weight, padding, dilation, stride):
@@ -236,17 +313,33 @@ class ModulatedDeformConvFunction(Function):
         ctx.groups = groups
         ctx.deformable_groups = deformable_groups
         ctx.with_bias = bias is not None
+        if not ctx.with_bias:
+            bias = input.new_empty(1)  # fake tensor, as the reference (deform_conv.py:131)
         if not input.is_cuda:
             raise NotImplementedError
+        if weight.requires_grad or mask.requires_grad or offset.requires_grad \
+                or input.requires_grad:
+            ctx.save_for_backward(input, offset, mask, weight, bias)
+        if not ctx.with_bias:
+            bias = None
         return deform_conv_forward(input, offset, weight, _pair(stride),
                                    _pair(padding), _pair(dilation), groups,
                                    deformable_groups, mask=mask, bias=bias)
 
     @staticmethod
     def backward(ctx, grad_output):
-        raise NotImplementedError(
-            'ganet_amd: modulated_deform_conv backward is not built '
-            '(inference hot path only)')
+        # deform_conv.py:152-172
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = deform_conv_backward(
+            input, offset, weight, grad_output, _pair(ctx.stride), _pair(ctx.padding),
+            _pair(ctx.dilation), ctx.groups, ctx.deformable_groups, mask=mask,
+            need_input=True, need_weight=True, need_bias=ctx.with_bias)
+        if not ctx.with_bias:
+            grad_bias = None
+        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias,
+                None, None, None, None, None)
 
     @staticmethod
     def _infer_shape(ctx, input, weight):

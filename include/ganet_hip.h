@@ -136,6 +136,32 @@ int ganet_deform_conv_forward(const void *x, const float *offset,
                               const ganet_dcn_params *p, void *workspace,
                               size_t workspace_bytes, ganet_stream_t stream);
 
+/* Backward (training), float32, conv groups == 1.
+ *
+ * Replaces deform_conv_backward_input_cuda + deform_conv_backward_parameters_cuda
+ * (mmdet/ops/dcn/src/cuda/deform_conv_cuda.cpp:262-488; called from
+ * DeformConvFunction.backward, mmdet/ops/dcn/deform_conv.py:60-96) and, with a mask,
+ * modulated_deform_conv_cuda_backward (deform_conv_cuda.cpp:571-700;
+ * ModulatedDeformConvFunction.backward, deform_conv.py:152-172).
+ *
+ * x, offset, mask, weight as in the forward call; grad_out has the forward output's
+ * shape and p->out_layout.  Like the reference, which adds into tensors its Python
+ * side zero-fills, grad_x [like x], grad_weight [like weight] and grad_bias [Cout] are
+ * ACCUMULATED INTO; grad_offset [like offset] and grad_mask [like mask] are overwritten.
+ * grad_x and grad_offset are computed together (both NULL to skip them, as when only
+ * the weight needs a gradient); grad_mask is required with them when mask != NULL;
+ * grad_weight and grad_bias may each be NULL.  There is no `columns` buffer and no
+ * im2col_step.  Unsupported (GANET_ERR_UNSUPPORTED): other dtypes, conv groups > 1,
+ * deformable groups whose channel count is not a multiple of 32, fuse_relu /
+ * offset_is_points / weight_is_packed. */
+size_t ganet_deform_conv_backward_workspace_bytes(const ganet_dcn_params *p);
+int ganet_deform_conv_backward(const void *x, const float *offset, const float *mask,
+                               const void *weight, const void *grad_out, void *grad_x,
+                               float *grad_offset, float *grad_mask, void *grad_weight,
+                               void *grad_bias, const ganet_dcn_params *p,
+                               void *workspace, size_t workspace_bytes,
+                               ganet_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * (2) Keypoint decode + lane grouping for a batch of images.
  *

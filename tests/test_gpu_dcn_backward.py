@@ -1,0 +1,121 @@
+"""GPU parity of the deform-conv backward, through the C-ABI, against the
+CPU oracle (oracle/ganet_oracle.c::oracle_deform_conv_backward, itself checked against
+autograd in tests/test_oracle_dcn.py).  float32; tolerance 1e-4 of each gradient's scale
+(fp32 atomic sums in an unspecified order on the GPU, double sums in the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from ganet_amd import _lib, dcn
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CASES = [
+    # B, Cin, H, W, Cout, kH, kW, stride, pad, dil, dg
+    (2, 64, 9, 13, 32, 1, 7, (1, 1), (0, 3), (1, 1), 1),      # LFA form, small
+    (1, 32, 10, 12, 16, 3, 3, (1, 1), (1, 1), (1, 1), 1),     # DCN 3x3
+    (2, 64, 11, 14, 24, 3, 3, (2, 2), (1, 1), (1, 1), 2),     # stride 2, 2 deformable groups
+    (1, 20, 12, 12, 8, 3, 3, (1, 1), (2, 2), (2, 2), 1),      # Cin padded to 32, dilation 2
+    (1, 32, 7, 9, 70, 1, 9, (1, 1), (0, 4), (1, 1), 1),       # Cout > 64 (two output blocks)
+    (3, 256, 8, 25, 64, 1, 7, (1, 1), (0, 3), (1, 1), 1),     # the LFA's channel counts
+]
+
+
+def make(case, seed, modulated):
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, kH, kW)) * 0.2).astype(np.float32)
+    Ho = O.dcn_out_size(H, pad[0], dil[0], kH, st[0])
+    Wo = O.dcn_out_size(W, pad[1], dil[1], kW, st[1])
+    off = (rng.standard_normal((B, dg * 2 * kH * kW, Ho, Wo)) * 1.7).astype(np.float32)
+    mask = rng.uniform(0.1, 1, (B, dg * kH * kW, Ho, Wo)).astype(np.float32) if modulated else None
+    go = rng.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)
+    return x, off, w, mask, go
+
+
+def close(got, ref, what):
+    got = got.detach().float().cpu().numpy()
+    assert got.shape == ref.shape, what
+    err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+    assert err <= TOL, "%s: relative error %.3g" % (what, err)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("modulated", [False, True])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_backward_matches_oracle(case, modulated, channels_last):
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 5, modulated)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg, mask=mask)
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo = (torch.from_numpy(a).to(dev) for a in (x, off, w, go))
+    tm = torch.from_numpy(mask).to(dev) if modulated else None
+    if channels_last:
+        tx = tx.contiguous(memory_format=torch.channels_last)
+        tgo = tgo.contiguous(memory_format=torch.channels_last)
+    gi, goff, gm, gw, gb = dcn.deform_conv_backward(
+        tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm, need_bias=modulated)
+    close(gi, ref["grad_x"], "grad_x")
+    close(goff, ref["grad_offset"], "grad_offset")
+    close(gw, ref["grad_weight"], "grad_weight")
+    if modulated:
+        close(gm, ref["grad_mask"], "grad_mask")
+        close(gb, ref["grad_bias"], "grad_bias")
+    assert gi.is_contiguous(memory_format=torch.channels_last) == (
+        channels_last and tx.is_contiguous(memory_format=torch.channels_last))
+
+
+def test_autograd_through_the_modules():
+    case = CASES[0]
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 9, True)
+    dev = torch.device("cuda", 0)
+    # DCNv1 module (DeformConv1D as the LFA uses it)
+    m = dcn.DeformConv1D(Cin, Cout, kW, stride=1, padding=pad[1], dilation=1).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.from_numpy(w))
+    tx = torch.from_numpy(x).to(dev).requires_grad_(True)
+    toff = torch.from_numpy(off).to(dev).requires_grad_(True)
+    out = m(tx, toff)
+    out.backward(torch.from_numpy(go).to(dev))
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg)
+    close(tx.grad, ref["grad_x"], "grad_x")
+    close(toff.grad, ref["grad_offset"], "grad_offset")
+    close(m.weight.grad, ref["grad_weight"], "grad_weight")
+    # weight-only gradient (input and offset detached)
+    m.weight.grad = None
+    m(tx.detach(), toff.detach()).backward(torch.from_numpy(go).to(dev))
+    close(m.weight.grad, ref["grad_weight"], "grad_weight (alone)")
+    # DCNv2 with bias
+    tb = torch.zeros(Cout, device=dev, requires_grad=True)
+    tw = torch.from_numpy(w).to(dev).requires_grad_(True)
+    tm = torch.from_numpy(mask).to(dev).requires_grad_(True)
+    tx.grad = toff.grad = None
+    out = dcn.modulated_deform_conv(tx, toff, tm, tw, tb, 1, pad, 1, 1, dg)
+    out.backward(torch.from_numpy(go).to(dev))
+    ref2 = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg, mask=mask)
+    close(tx.grad, ref2["grad_x"], "v2 grad_x")
+    close(toff.grad, ref2["grad_offset"], "v2 grad_offset")
+    close(tm.grad, ref2["grad_mask"], "v2 grad_mask")
+    close(tw.grad, ref2["grad_weight"], "v2 grad_weight")
+    close(tb.grad, ref2["grad_bias"], "v2 grad_bias")
+
+
+def test_backward_rejects_what_it_does_not_build():
+    dev = torch.device("cuda", 0)
+    x = torch.zeros(1, 32, 6, 6, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        dcn.deform_conv_backward(x, torch.zeros(1, 18, 6, 6, device=dev),
+                                 torch.zeros(8, 32, 3, 3, device=dev, dtype=torch.bfloat16),
+                                 torch.zeros(1, 8, 6, 6, device=dev, dtype=torch.bfloat16),
+                                 (1, 1), (1, 1), (1, 1))
+    # conv groups > 1 and deformable groups of 16 channels: status UNSUPPORTED
+    x = torch.zeros(1, 32, 6, 6, device=dev)
+    with pytest.raises(_lib.GanetError):
+        dcn.deform_conv_backward(x, torch.zeros(1, 36, 6, 6, device=dev),
+                                 torch.zeros(8, 32, 3, 3, device=dev),
+                                 torch.zeros(1, 8, 6, 6, device=dev), (1, 1), (1, 1), (1, 1),
+                                 1, 2)
