@@ -159,6 +159,28 @@ class HotPath(object):
         self.lfa(x, pts)
         self.decode(heat, offset, error)
 
+    def capture(self, x, pts, heat, offset, error):
+        """Record one step on these (fixed) input tensors into a HIP graph and return
+        it; `graph.replay()` then enqueues the whole step with one host call (at batch 1
+        the host launch cost is a quarter of the step).  The step allocates nothing and
+        never synchronises, so it captures as it stands; `result()` works after a replay
+        as after `step()`."""
+        assert not self.overlap_copy, "capture needs the single-stream flow"
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):       # warm-up outside the capture
+            self.step(x, pts, heat, offset, error)
+        cur.wait_stream(side)
+        cur.synchronize()
+        first = self.cur
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.cur = first                # the graph always writes this result block
+            self.step(x, pts, heat, offset, error)
+        self.cur = first ^ 1
+        return graph
+
     def result(self):
         """Wait for the last step's copy and view its decode result."""
         torch.cuda.current_stream(self.device).synchronize()

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Times the deform-conv backward at the LFA's shapes (fp32, training): images/s for
+grad_input+grad_offset and grad_weight, beside the forward.  Not the headline metric;
+tools/ only.  Usage: python tools/bench_backward.py [--batch 32] [--steps 20]"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from ganet_amd import dcn, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--channels-last", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    B, Cin, H, W, K, Cout = args.batch, 256, 40, 100, 7, 64
+    x, off, w, _ = synth.lfa_inputs(B, Cin, H, W, K, Cout=Cout, seed=0)
+    tx, toff, tw = (torch.from_numpy(a).to(dev) for a in (x, off, w))
+    if args.channels_last:
+        tx = tx.contiguous(memory_format=torch.channels_last)
+    out = dcn.deform_conv_forward(tx, toff, tw, (1, 1), (0, 3), (1, 1))
+    go = torch.randn_like(out)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.steps
+
+    t_f = timed(lambda: dcn.deform_conv_forward(tx, toff, tw, (1, 1), (0, 3), (1, 1)))
+    t_i = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, 3), (1, 1),
+                                                 need_input=True, need_weight=False))
+    t_w = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, 3), (1, 1),
+                                                 need_input=False, need_weight=True))
+    print(json.dumps(dict(batch=B, channels_last=args.channels_last, forward_ms=t_f,
+                          backward_input_ms=t_i, backward_weight_ms=t_w,
+                          train_images_per_s=B / ((t_f + t_i + t_w) * 1e-3))))
+
+
+if __name__ == "__main__":
+    main()
