@@ -153,6 +153,10 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="profiling only")
     ap.add_argument("--algo", type=int, default=0,
                     help="LFA algorithm: 0 auto, 1 sample-then-contract, 2 contract-then-sample")
+    ap.add_argument("--fp32-mode", default="auto", choices=["auto", "bf16", "exact"],
+                    help="fp32 tensors: auto = float32-class accuracy (three bf16 MFMA passes "
+                         "over hi/lo splits where the contract-then-sample path applies), "
+                         "bf16 = one bf16 pass, exact = float32 MFMA only")
     ap.add_argument("--pts", default="synthetic", choices=["synthetic", "zero"])
     ap.add_argument("--device-pack", action="store_true",
                     help="pack in device memory and copy D2H (default: the pack kernel "
@@ -196,6 +200,7 @@ def main():
                  thr=cfg["thr"], root_thr=cfg["root_thr"], cluster_thr=T, by_center_thr=T,
                  max_kpts=min(H * W, 4096 if cfg["lanes"] > 4 else 1024),
                  max_centers=256, overlap_copy=args.overlap_copy,
+                 mfma_bf16={"auto": 0, "bf16": 1, "exact": 2}[args.fp32_mode],
                  ablate=args.ablate, algo=args.algo, pack_to_host=not args.device_pack)
     if args.pts == "zero":
         d["pts"].zero_()
@@ -265,8 +270,18 @@ def main():
 
     if rank == 0:
         nbytes, flops = lfa_algorithmic(B, Cin, 64, H, W, K, dtype)
+        # float32 tensors on algorithm 2 are contracted as three bf16 MFMA passes
+        # (hi*hi + hi*lo + lo*hi): price the matrix work as 3x the FLOPs at the bf16 peak
+        split = dtype == "fp32" and hp.lfa_algorithm == 2 and args.fp32_mode == "auto"
+        arith = dtype
+        if split:
+            flops *= 3.0
+            arith = "bf16"
+        elif dtype == "fp32" and args.fp32_mode == "bf16":
+            arith = "bf16"
+        peak_tflops = MFMA_PEAK_TFLOPS[arith]
         t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
-        t_mfma = flops / (MFMA_PEAK_TFLOPS[dtype] * 1e12)
+        t_mfma = flops / (peak_tflops * 1e12)
         lfa_s = lfa_ms * 1e-3
         hbm_achieved = nbytes / lfa_s / 1e9
         mfma_achieved = flops / lfa_s / 1e12
@@ -279,18 +294,21 @@ def main():
                 traffic = None
         if t_mfma >= t_hbm:
             roof = dict(bound="mfma", achieved=mfma_achieved,
-                        peak=MFMA_PEAK_TFLOPS[dtype], unit="TFLOP/s",
-                        frac=mfma_achieved / MFMA_PEAK_TFLOPS[dtype])
+                        peak=peak_tflops, unit="TFLOP/s",
+                        frac=mfma_achieved / peak_tflops)
         else:
             roof = dict(bound="hbm", achieved=hbm_achieved, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=hbm_achieved / HBM_PEAK_GBS)
         kernels = ("dcn_fused_kernel" if hp.lfa_algorithm == 1 else
-                   "cts_gemm_kernel + cts_sample_kernel (all chunk pairs of one LFA launch)")
+                   "%s + cts_sample_kernel (all chunk pairs of one LFA launch)"
+                   % ("cts_gemm_split_kernel" if split else "cts_gemm_kernel"))
         roof.update(traffic=traffic, kernel=kernels, lfa_algorithm=hp.lfa_algorithm,
                     kernel_ms=lfa_ms, algorithmic_bytes=nbytes, algorithmic_flops=flops,
                     hbm_gbs=hbm_achieved, hbm_frac=hbm_achieved / HBM_PEAK_GBS,
                     mfma_tflops=mfma_achieved,
-                    mfma_frac=mfma_achieved / MFMA_PEAK_TFLOPS[dtype],
+                    mfma_frac=mfma_achieved / peak_tflops,
+                    mfma_arithmetic=("3 bf16 passes over hi/lo splits, fp32 accumulate"
+                                     if split else arith),
                     roofline_time_frac=max(t_hbm, t_mfma) / lfa_s)
         out = {
             "metric": "images/sec (LFA+decode, 320x800)" if wl["decode"]
@@ -310,6 +328,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B,
                        "feature_hw": [H, W], "cin": Cin, "cout": 64, "k": K,
                        "layout": "NHWC (channels_last) resident in HBM",
+                       "fp32_mode": args.fp32_mode if dtype == "fp32" else None,
                        "launch": "hip graph replay" if graph is not None else "eager",
                        "parallelism": "image-sharded x%d, no collective" % world},
             "roofline": roof,

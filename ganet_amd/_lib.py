@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libganet_hip.so")
+# GANET_HIP_LIB: another build of the same library (tools/variants.py, tuning runs)
+LIB_PATH = os.environ.get("GANET_HIP_LIB") or os.path.join(_HERE, "libganet_hip.so")
 
 GANET_OK = 0
 GANET_ERR_NULL = -1

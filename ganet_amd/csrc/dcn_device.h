@@ -119,6 +119,9 @@ struct Mma<f16_t> {
 
 // contract-then-sample path (csrc/deform_conv_cts.hip)
 bool cts_applicable(const ganet_dcn_params *p, int Cp, int CoutP);
+// float32 tensors whose per-tap GEMM runs as three bf16 passes (weights packed as
+// a high and a low bf16 plane)
+bool cts_split(const ganet_dcn_params *p, int Cp);
 size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta);
 int cts_forward(const void *xh, const float *offset, const float *mask, const void *wq,
                 const void *bias, void *out, const ganet_dcn_params *p, int ta, int kc,

@@ -556,6 +556,25 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(
   }
 }
 
+// W[Cout][Cin][T] float32 -> two bf16 planes Wp[T][CoutP][Cp]: hi = bf16(w), then
+// lo = bf16(w - hi)  (cts_gemm_split_kernel, deform_conv_cts.hip)
+__global__ __launch_bounds__(256) void pack_weight_split_kernel(
+    const float *__restrict__ w, bf16_t *__restrict__ wp, int Cout, int Cin, int T,
+    int CoutP, int Cp) {
+  const long long total = (long long)T * CoutP * Cp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % Cp);
+    const int o = (int)((i / Cp) % CoutP);
+    const int t = (int)(i / ((long long)Cp * CoutP));
+    float v = 0.f;
+    if (o < Cout && c < Cin) v = w[((size_t)o * Cin + c) * T + t];
+    const bf16_t hi = from_f32<bf16_t>(v);
+    wp[i] = hi;
+    wp[total + i] = from_f32<bf16_t>(v - to_f32(hi));
+  }
+}
+
 // ---- host side ------------------------------------------------------------------
 
 struct Plan {
@@ -566,6 +585,7 @@ struct Plan {
   int Cp, CoutP;
   bool copy_x;   // a channel-last (and/or converted, padded) copy of x is made
   bool cts;      // contract-then-sample path (deform_conv_cts.hip)
+  bool split;    // ... with float32 tensors contracted as three bf16 passes
   size_t xh_bytes, wp_bytes, y_bytes;
 };
 
@@ -600,7 +620,8 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
     return GANET_ERR_UNSUPPORTED;
   pl->T = p->kH * p->kW;
   pl->ta_dummy = 0;
-  pl->ta = (p->dtype == GANET_F32 && p->mfma_bf16) ? GANET_BF16 : p->dtype;
+  if (p->mfma_bf16 < 0 || p->mfma_bf16 > 2) return GANET_ERR_BAD_SHAPE;
+  pl->ta = (p->dtype == GANET_F32 && p->mfma_bf16 == 1) ? GANET_BF16 : p->dtype;
   // weight chunk (channels): 512 B per output row when the channel count allows,
   // else 256 B / 128 B; channels are zero-padded to the smallest chunk otherwise
   const int kc_big = pl->ta == GANET_F32 ? 128 : 256;
@@ -640,6 +661,7 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
   // that have to be gathered and blended (Cout < Cin, as in the LFA).
   pl->cts = cts_applicable(p, pl->Cp, pl->CoutP) && p->algo != 1;
   if (p->algo == 2 && !pl->cts) return GANET_ERR_UNSUPPORTED;
+  pl->split = pl->cts && pl->ta == GANET_F32 && cts_split(p, pl->Cp);
   pl->y_bytes = pl->cts ? cts_y_bytes(p, pl->CoutP, pl->ta) : 0;
   return GANET_OK;
 }
@@ -733,7 +755,13 @@ extern "C" size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *
 namespace {
 int pack_weight_dispatch(const ganet_dcn_params *p, const Plan &pl,
                          const void *weight, void *wp, hipStream_t s) {
-  if (p->dtype == GANET_F32 && pl.ta == GANET_F32)
+  if (pl.split) {
+    const long long total = (long long)pl.T * pl.CoutP * pl.Cp;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_split_kernel, dim3(blocks), dim3(256), 0, s,
+                       static_cast<const float *>(weight), static_cast<bf16_t *>(wp),
+                       p->Cout, p->Cin, pl.T, pl.CoutP, pl.Cp);
+  } else if (p->dtype == GANET_F32 && pl.ta == GANET_F32)
     launch_pack_weight<float, float>(p, pl, weight, wp, s);
   else if (p->dtype == GANET_F32 && pl.ta == GANET_BF16)
     launch_pack_weight<float, bf16_t>(p, pl, weight, wp, s);

@@ -245,6 +245,155 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
 #endif
 }
 
+// ---- Y = X * Wq^T for float32 tensors, on the bf16 matrix cores in three passes ------
+// x [M][Cp] float32, wq = two bf16 planes [N][Cp] (high parts, then low parts), y [M][N]
+// float32.  Every float is split as v = hi + lo with hi = bf16(v), lo = bf16(v - hi)
+// (|v - hi - lo| <= 2^-18 |v|), and x*w is formed as hi*hi + hi*lo + lo*hi with float32
+// accumulation: products exact, the dropped lo*lo term and the split residues are
+// <= 3 * 2^-18 relative per product (measured 4e-6 of the output scale at K = 1792) -
+// float32-class accuracy at 3/16 of the float32 MFMA's time (it runs at the vector rate).
+// Non-finite inputs give NaN (inf - inf in the split) where exact arithmetic may give inf.
+// Same structure as cts_gemm_kernel with one 32-row block per wavefront (its high and low
+// fragments fill the registers two blocks took there) and 32-column slices.
+template <int KH>
+__global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_split_kernel(
+    const float *__restrict__ x, const bf16_t *__restrict__ wq, float *__restrict__ y,
+    long long M, int Cp, int N, int slices_per_block) {
+  constexpr int EPL = 8;
+  constexpr int NQ = KH / 16;
+  constexpr int LDB = KH + EPL;
+  constexpr int SB = 32;                      // output columns per slice
+  constexpr int P_BYTES = SB * LDB * 2;       // one plane of one slice
+  constexpr int B_BYTES = 2 * P_BYTES;        // high + low
+  constexpr int NT = GEMM_WAVES * 64;
+  constexpr int YROW = SB * 4 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * B_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char s_y[GEMM_WAVES * 32 * YROW];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const long long m0 = ((long long)blockIdx.x * GEMM_WAVES + wid) * 32;
+  const long long r = m0 + i;
+  const float *xrow = x + (r < M ? r : M - 1) * Cp + h * EPL;
+
+  const int kchunks = Cp / KH;
+  const int slice0 = blockIdx.y * slices_per_block;
+  const int nslices = min(slices_per_block, N / SB - slice0);
+  const int total = nslices * kchunks;
+  const bf16_t *wq_lo = wq + (size_t)N * Cp;
+  y += (size_t)slice0 * SB;
+
+  constexpr int PPP = SB * (KH / EPL);        // 16-byte pieces per plane and slice
+  constexpr int BPT = 2 * PPP / NT;
+  static_assert((2 * PPP) % NT == 0, "weight slice must split evenly over the threads");
+  u32x4 breg[BPT];
+  auto load_b = [&](int it) {
+    const int n = slice0 + it / kchunks, kc = it % kchunks;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NT;
+      const int pl = q / PPP, q2 = q - pl * PPP;
+      const int rr = q2 / (KH / EPL), pc = q2 - rr * (KH / EPL);
+      breg[j] = ldg128((pl ? wq_lo : wq) + ((size_t)(n * SB + rr) * Cp + kc * KH + pc * EPL));
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NT;
+      const int pl = q / PPP, q2 = q - pl * PPP;
+      const int rr = q2 / (KH / EPL), pc = q2 - rr * (KH / EPL);
+      *reinterpret_cast<u32x4 *>(s_b + buf * B_BYTES + pl * P_BYTES +
+                                 (rr * LDB + pc * EPL) * 2) = breg[j];
+    }
+  };
+
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x8 fa_hi[NQ], fa_lo[NQ];
+  auto load_a = [&](int kc) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const u32x4 v0 = ldg128(xrow + kc * KH + q * 16);
+      const u32x4 v1 = ldg128(xrow + kc * KH + q * 16 + 4);
+      unsigned int hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a0 = __uint_as_float(e < 2 ? v0[2 * e] : v1[2 * e - 4]);
+        const float a1 = __uint_as_float(e < 2 ? v0[2 * e + 1] : v1[2 * e - 3]);
+        const bf16x2 ph = {(__bf16)a0, (__bf16)a1};
+        const unsigned int uh = __builtin_bit_cast(unsigned int, ph);
+        const float r0 = a0 - __uint_as_float(uh << 16);
+        const float r1 = a1 - __uint_as_float(uh & 0xffff0000u);
+        const bf16x2 pl = {(__bf16)r0, (__bf16)r1};
+        hi[e] = uh;
+        lo[e] = __builtin_bit_cast(unsigned int, pl);
+      }
+      const u32x4 ph4 = {hi[0], hi[1], hi[2], hi[3]};
+      const u32x4 pl4 = {lo[0], lo[1], lo[2], lo[3]};
+      fa_hi[q] = __builtin_bit_cast(bf16x8, ph4);
+      fa_lo[q] = __builtin_bit_cast(bf16x8, pl4);
+    }
+  };
+
+  load_b(0);
+  load_a(0);
+  store_b(0);
+
+  f32x16 acc;
+  for (int it = 0; it < total; ++it) {
+    const int n = it / kchunks, kc = it - n * kchunks;
+    const bool more = it + 1 < total;
+    __syncthreads();  // slice `it` is in its buffer; the other buffer is free again
+    if (more) load_b(it + 1);
+    if (kchunks > 1 && it > 0) load_a(kc);
+    if (kc == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    }
+    {
+      const unsigned char *Bs = s_b + (it & 1) * B_BYTES;
+      const bf16_t *bh = reinterpret_cast<const bf16_t *>(Bs) + i * LDB + h * EPL;
+      const bf16_t *bl = reinterpret_cast<const bf16_t *>(Bs + P_BYTES) + i * LDB + h * EPL;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const bf16x8 fh = *reinterpret_cast<const bf16x8 *>(bh + q * 16);
+        const bf16x8 fl = *reinterpret_cast<const bf16x8 *>(bl + q * 16);
+        // rows = outputs, columns = pixels; small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, fa_hi[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fa_lo[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fa_hi[q], acc, 0, 0, 0);
+      }
+    }
+    if (more) store_b((it + 1) & 1);
+    if (kc == kchunks - 1) {
+      // lane (i, h), registers 4g..4g+3 hold outputs 8g + 4h + 0..3 of pixel i
+      unsigned char *ys = s_y + wid * 32 * YROW;
+      float *yr = reinterpret_cast<float *>(ys + i * YROW) + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *reinterpret_cast<f32x4 *>(yr + 8 * g) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int pc = lane & 7, rq = lane >> 3;   // 8 lanes x 16 B per 32-float row
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int rr = ps * 8 + rq;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
+        const long long mr = m0 + rr;
+        if (mr < M)
+          *reinterpret_cast<u32x4 *>(y + mr * N + (size_t)n * SB + pc * 4) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
 // ---- out = sum over taps of bilinear samples of Y -----------------------------------
 struct SampleArgs {
   const void *y;        // [nimg*H*W][T*CoutP], first image of the chunk at row 0
@@ -326,8 +475,34 @@ __global__ __launch_bounds__(SAMPLE_WAVES * 64) void cts_sample_kernel(SampleArg
   const long long xbeg = xcd * per_xcd;
   const long long xend = xbeg + per_xcd < ngroups ? xbeg + per_xcd : ngroups;
   const long long xstride = (long long)(gridDim.x >> 3) * SAMPLE_WAVES;
-  for (long long grp = xbeg + (long long)(blockIdx.x >> 3) * SAMPLE_WAVES + wid; grp < xend;
-       grp += xstride) {
+  // offsets (and mask) of this lane's taps of one pixel group, tap block t0
+  constexpr int KPL = TAP_BLOCK / LPX;     // taps per lane and block
+  auto load_offsets = [&](long long grp, int t0, float *oh, float *ow, float *mk) {
+    const long long p = grp * PPW + pj;
+    const bool valid = p < P && grp < xend;
+    const int bl = valid ? (int)(p / HWo) : 0;
+    const int hw = valid ? (int)(p - (long long)bl * HWo) : 0;
+    const int b = a.img0 + bl;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      const int t = t0 + piece + k * LPX;
+      oh[k] = ow[k] = 0.f;
+      mk[k] = 1.f;
+      if (valid && t < a.T) {
+        const float *op = a.offset + ((size_t)b * 2 * a.T + 2 * t) * HWo + hw;
+        oh[k] = ldg_f32(op);
+        ow[k] = ldg_f32(op + HWo);
+        if (a.mask) mk[k] = ldg_f32(a.mask + ((size_t)b * a.T + t) * HWo + hw);
+      }
+    }
+  };
+  // the first tap block's offsets of the NEXT group are fetched while this group's
+  // gathers are in flight: a wave walks only a handful of groups, each a chain of
+  // offsets -> coordinates -> gather -> store, and this takes one link off it
+  float nh[KPL], nw[KPL], nm[KPL];
+  const long long grp0 = xbeg + (long long)(blockIdx.x >> 3) * SAMPLE_WAVES + wid;
+  load_offsets(grp0, 0, nh, nw, nm);
+  for (long long grp = grp0; grp < xend; grp += xstride) {
     const long long p = grp * PPW + pj;
     const bool valid = p < P;
     const int bl = valid ? (int)(p / HWo) : 0;            // image within the chunk
@@ -342,17 +517,29 @@ __global__ __launch_bounds__(SAMPLE_WAVES * 64) void cts_sample_kernel(SampleArg
     for (int t0 = 0; t0 < a.T; t0 += TAP_BLOCK) {
       const int nt = min(TAP_BLOCK, a.T - t0);
       // the LPX lanes of a pixel split the taps of this block
-      for (int tt = piece; tt < nt; tt += LPX) {
+      float ch[KPL], cw[KPL], cm[KPL];
+      if (t0 == 0) {
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+          ch[k] = nh[k];
+          cw[k] = nw[k];
+          cm[k] = nm[k];
+        }
+      } else {
+        load_offsets(grp, t0, ch, cw, cm);
+      }
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        const int tt = piece + k * LPX;
+        if (tt >= nt) break;
         const int t = t0 + tt;
         const int ti = t / a.kW, tj = t - ti * a.kW;
         unsigned c1 = OOB_OFFSET, c2 = OOB_OFFSET, c3 = OOB_OFFSET, c4 = OOB_OFFSET;
         float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
         if (valid) {
-          const float *op = a.offset + ((size_t)b * 2 * a.T + 2 * t) * HWo + hw;
-          float off_h = ldg_f32(op);
-          float off_w = ldg_f32(op + HWo);
-          float mk = 1.f;
-          if (a.mask) mk = ldg_f32(a.mask + ((size_t)b * a.T + t) * HWo + hw);
+          const float off_h = ch[k];
+          float off_w = cw[k];
+          const float mk = cm[k];
           if (a.points)  // dcn_offset = pts - base  (lanepoints_conv.py:63-74,170)
             off_w = off_w - (float)(tj - a.pW);
           const float h_im = (float)(ho * a.sH - a.pH + ti * a.dH) + off_h;
@@ -383,6 +570,7 @@ __global__ __launch_bounds__(SAMPLE_WAVES * 64) void cts_sample_kernel(SampleArg
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (t0 == 0) load_offsets(grp + xstride, 0, nh, nw, nm);
 #pragma unroll 2
       for (int tt = 0; tt < nt; ++tt) {
         const uint4 cx = *reinterpret_cast<const uint4 *>(s_off[wid][pj][tt]);
@@ -479,6 +667,28 @@ void launch_gemm(int kh, const void *x, const void *wq, void *y, long long M, in
     launch_gemm_rb<TA, TY, 1>(kh, x, wq, y, M, Cp, N, ablate, s);
 }
 
+void launch_gemm_split(const void *x, const void *wq, void *y, long long M, int Cp, int N,
+                       hipStream_t s) {
+  constexpr int ROWS = GEMM_WAVES * 32;
+  const unsigned gx = (unsigned)((M + ROWS - 1) / ROWS);
+  const int nslices = N / 32;
+  int ny = gx > 64 ? 1 : (int)((256 + gx - 1) / gx);
+  if (ny > nslices) ny = nslices;
+  const int per = (nslices + ny - 1) / ny;
+  ny = (nslices + per - 1) / per;
+  dim3 grid(gx, (unsigned)ny);
+  dim3 block(GEMM_WAVES * 64);
+  const float *xx = static_cast<const float *>(x);
+  const bf16_t *ww = static_cast<const bf16_t *>(wq);
+  float *yy = static_cast<float *>(y);
+  if (Cp % 256 == 0)
+    hipLaunchKernelGGL((cts_gemm_split_kernel<256>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+  else if (Cp % 128 == 0)
+    hipLaunchKernelGGL((cts_gemm_split_kernel<128>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+  else
+    hipLaunchKernelGGL((cts_gemm_split_kernel<64>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+}
+
 template <typename TY, typename TO>
 void launch_sample(const SampleArgs &a, hipStream_t s) {
   constexpr int PPW = 64 / (64 / (16 / (int)sizeof(TY)));
@@ -497,10 +707,16 @@ void launch_sample(const SampleArgs &a, hipStream_t s) {
 
 // Applicable when the commuted order is cheaper and its assumptions hold: one
 // deformable group (one Y per tap) and fewer output than input channels.
+bool cts_split(const ganet_dcn_params *p, int Cp) {
+  return p->dtype == GANET_F32 && p->mfma_bf16 == 0 && Cp % 64 == 0;
+}
+
 bool cts_applicable(const ganet_dcn_params *p, int Cp, int CoutP) {
-  // fp32: the per-tap GEMM alone costs what the fused kernel costs in total
-  // (fp32 MFMA runs at the vector rate), so only the 16-bit paths commute.
-  if (p->dtype == GANET_F32 && !p->mfma_bf16 && p->algo != 2) return false;
+  // float32: with the float32 MFMA (it runs at the vector rate) the per-tap GEMM alone
+  // costs what the fused kernel costs in total, so float32 tensors commute only when
+  // the GEMM may run as three bf16 passes (cts_split) or the caller asks for it.
+  if (p->dtype == GANET_F32 && p->mfma_bf16 != 1 && !cts_split(p, Cp) && p->algo != 2)
+    return false;
   return p->deformable_groups == 1 && p->groups == 1 && 2 * CoutP <= Cp &&
          p->sH == 1 && p->sW == 1 && p->kH * p->kW <= 64;
 }
@@ -530,6 +746,7 @@ size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta) {
 int cts_forward(const void *xh, const float *offset, const float *mask, const void *wq,
                 const void *bias, void *out, const ganet_dcn_params *p, int ta, int kc,
                 int Cp, int CoutP, int Ho, int Wo, void *ybuf, hipStream_t s) {
+  const bool split = ta == GANET_F32 && cts_split(p, Cp);
   const int T = p->kH * p->kW;
   const int N = T * CoutP;
   const size_t es = ta == GANET_F32 ? 4 : 2;
@@ -542,7 +759,9 @@ int cts_forward(const void *xh, const float *offset, const float *mask, const vo
     const long long M = (long long)nimg * p->H * p->W;
     const unsigned char *xc =
         static_cast<const unsigned char *>(xh) + (size_t)img0 * p->H * p->W * Cp * es;
-    if (ta == GANET_F32)
+    if (split)
+      launch_gemm_split(xc, wq, ybuf, M, Cp, N, s);
+    else if (ta == GANET_F32)
       launch_gemm<float, float>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
     else if (ta == GANET_BF16)
       launch_gemm<bf16_t, bf16_t>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);

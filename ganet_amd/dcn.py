@@ -26,9 +26,14 @@ _DTYPES = {torch.float32: _lib.GANET_F32, torch.bfloat16: _lib.GANET_BF16,
 
 
 class _Config(object):
-    """mfma_bf16: contract float32 inputs on the bf16 matrix cores (fp32
-    accumulate, ~1e-2 relative error) instead of the exact-fp32 MFMA."""
+    """How float32 tensors are contracted (ganet_dcn_params.mfma_bf16):
+    default - float32-class accuracy: the exact float32 MFMA, or, where the
+    contract-then-sample algorithm applies (the LFA's 256 -> 64), three bf16 MFMA
+    passes over hi/lo splits of both operands (~4e-6 of the output scale);
+    mfma_bf16 = True - operands rounded to bf16, one pass (~1e-2);
+    exact_fp32 = True - the float32 MFMA only."""
     mfma_bf16 = False
+    exact_fp32 = False
     # Re-use the kernel-layout copy of a weight across calls while the tensor's
     # (data_ptr, _version) is unchanged.  Off by default: writes through
     # `weight.data` do not bump `_version`, so a stale copy could be used.
@@ -110,7 +115,12 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
     p.x_layout = _lib.GANET_NHWC if nhwc else _lib.GANET_NCHW
     p.out_layout = p.x_layout
     use_bf16 = config.mfma_bf16 if mfma_bf16 is None else mfma_bf16
-    p.mfma_bf16 = 1 if (use_bf16 and input.dtype == torch.float32) else 0
+    if input.dtype != torch.float32:
+        p.mfma_bf16 = 0
+    elif use_bf16 == "exact" or (not use_bf16 and config.exact_fp32):
+        p.mfma_bf16 = 2
+    else:
+        p.mfma_bf16 = 1 if use_bf16 else 0
     p.fuse_relu = 1 if fuse_relu else 0
     p.offset_is_points = 1 if offset_is_points else 0
     p.algo = algo

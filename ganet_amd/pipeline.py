@@ -40,7 +40,9 @@ class HotPath(object):
         p.groups = p.deformable_groups = 1
         p.dtype = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
         p.x_layout = p.out_layout = 1 if channels_last else 0
-        p.mfma_bf16 = 1 if (mfma_bf16 and dtype == torch.float32) else 0
+        # float32 only: 0 float32-class accuracy (may use three bf16 passes), 1 one bf16
+        # pass, 2 exact float32 MFMA (ganet_dcn_params.mfma_bf16)
+        p.mfma_bf16 = int(mfma_bf16) if dtype == torch.float32 else 0
         p.fuse_relu = 1 if fuse_relu else 0
         p.offset_is_points = 1 if offset_is_points else 0
         p.weight_is_packed = 1

@@ -76,10 +76,17 @@ typedef struct {
                                mask are always float32. */
   int32_t x_layout;         /* ganet_layout of x */
   int32_t out_layout;       /* ganet_layout of out */
-  int32_t mfma_bf16;        /* dtype == GANET_F32 only: 1 = round the sampled
-                               columns and the weights to bf16 and contract on
-                               the bf16 MFMA (fp32 accumulate); 0 = exact-fp32
-                               MFMA */
+  int32_t mfma_bf16;        /* dtype == GANET_F32 only, how float32 tensors are
+                               contracted:
+                               0 = float32-class accuracy (default): the exact
+                                   float32 MFMA, or - where algorithm 2 applies -
+                                   three bf16 MFMA passes over hi/lo splits of
+                                   both operands with float32 accumulation
+                                   (<= 3*2^-18 relative per product, ~4e-6 of the
+                                   output scale; non-finite inputs give NaN);
+                               1 = round operands to bf16, one bf16 MFMA pass
+                                   (~1e-2 of the output scale);
+                               2 = exact float32 MFMA only */
   int32_t fuse_relu;        /* 1 = out = max(out, 0)
                                (mmdet/models/dense_heads/lanepoints_conv.py:172) */
   int32_t offset_is_points; /* 1 = `offset` holds the LFA's pts_out_init and the

@@ -156,6 +156,38 @@ def test_fp32_storage_bf16_mfma():
     assert rel_err(exact, ref) <= TOL_F32
 
 
+SPLIT_CASES = [
+    # float32 shapes that take the three-pass bf16 split GEMM (Cin % 64 == 0, 2*Cout <= Cin)
+    (2, 256, 12, 20, 64, 1, 7, (1, 1), (0, 3), (1, 1), 1),    # one 256-channel K chunk
+    (1, 512, 9, 13, 64, 1, 7, (1, 1), (0, 3), (1, 1), 1),     # two K chunks of 256
+    (1, 320, 10, 12, 96, 3, 3, (1, 1), (1, 1), (1, 1), 1),    # five K chunks of 64, padded Cout
+    (1, 128, 33, 47, 32, 1, 9, (1, 1), (0, 4), (1, 1), 1),    # row tiles with a ragged tail
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_fp32_modes_split_exact_bf16(case):
+    """ganet_dcn_params.mfma_bf16: 0 (default) contracts float32 tensors as three bf16 MFMA
+    passes over hi/lo splits where algorithm 2 applies, 2 keeps the exact float32 MFMA;
+    both must meet the float32 tolerance, also on inputs with a wide dynamic range."""
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w = make(*case, seed=5)
+    rng = np.random.default_rng(5)
+    x *= np.exp(rng.uniform(-6, 6, (B, 1, H, W))).astype(np.float32)   # per-pixel scales e^-6..e^6
+    ref = O.deform_conv_forward(x, off, w, st, pad, dil, 1, dg, acc64=True, nthreads=4)
+    errs = {}
+    for mode, algo in ((False, 0), (False, 2), ("exact", 0), ("exact", 2)):
+        for cl in (False, True):
+            got = run_gpu(x, off, w, st, pad, dil, dg, channels_last=cl, mfma_bf16=mode,
+                          algo=algo)
+            errs[(mode, algo, cl)] = rel_err(got, ref)
+    assert max(errs.values()) <= TOL_F32, errs
+    # the split really ran: it is not bit-identical to the exact path, yet far inside 1e-4
+    assert errs[(False, 0, True)] <= 2e-5, errs
+    one_pass = run_gpu(x, off, w, st, pad, dil, dg, mfma_bf16=True)
+    assert TOL_F32 < rel_err(one_pass, ref) <= TOL_16
+
+
 @pytest.mark.parametrize("shape,B,Cin", [("s8_tusimple", 2, 256), ("s8_tusimple", 3, 64),
                                          ("s4_culane", 1, 256)])
 def test_lfa_shapes_fp32_and_bf16(shape, B, Cin):
