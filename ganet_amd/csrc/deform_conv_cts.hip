@@ -32,7 +32,10 @@ namespace ganet_dcn {
 
 namespace {
 
-constexpr int GEMM_WAVES = 8;
+#ifndef GANET_GEMM_WAVES
+#define GANET_GEMM_WAVES 8
+#endif
+constexpr int GEMM_WAVES = GANET_GEMM_WAVES;
 constexpr int SAMPLE_WAVES = 4;
 constexpr int TAP_BLOCK = 16;   // taps whose coordinates sit in LDS at a time
 
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
     printf("\n");
   }
 #endif
+#undef GANET_STAMP
 }
 
 // ---- Y = X * Wq^T for float32 tensors, on the bf16 matrix cores in three passes ------
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
 template <int KH>
 __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_split_kernel(
     const float *__restrict__ x, const bf16_t *__restrict__ wq, float *__restrict__ y,
-    long long M, int Cp, int N, int slices_per_block) {
+    long long M, int Cp, int N, int slices_per_block, int ablate) {
   constexpr int EPL = 8;
   constexpr int NQ = KH / 16;
   constexpr int LDB = KH + EPL;
@@ -336,22 +340,75 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_split_kernel(
     }
   };
 
+  // The finished 32x32 block of slice n leaves while slice n+1 is contracted: two
+  // accumulators alternate, and the staging writes / row reads / global stores of the
+  // previous block sit between the MFMAs of the next one (both waves of a SIMD stop at the
+  // same workgroup barriers, so work left between barrier and MFMAs idles the matrix pipe).
+  unsigned char *ys = s_y + wid * 32 * YROW;
+  const __amdgpu_buffer_rsrc_t ydst = __builtin_amdgcn_make_buffer_rsrc(
+      y, 0, (int)(((size_t)M * N - (size_t)slice0 * SB) * 4), 0x00020000);
+  // lane (i, h), registers 4g..4g+3 hold outputs 8g + 4h + 0..3 of pixel i
+  auto stage_write = [&](const f32x16 &acc) {
+    float *yr = reinterpret_cast<float *>(ys + i * YROW) + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      *reinterpret_cast<f32x4 *>(yr + 8 * g) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto stage_store = [&](int n) {
+    const int pc = lane & 7, rq = lane >> 3;   // 8 lanes x 16 B per 32-float row
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int rr = ps * 8 + rq;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
+      const long long mr = m0 + rr;
+      // buffer stores without a branch (rows past M fall outside the window and are
+      // dropped): the compiler can then count them, and the wait for the weight loads
+      // issued before them does not wait for these stores to complete
+      const unsigned off = mr < M ? (unsigned)((mr * N + n * SB + pc * 4) * 4) : OOB_OFFSET;
+      __builtin_amdgcn_raw_buffer_store_b128(v, ydst, off, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+#ifdef GANET_ABLATE
+  unsigned long long ts[80];
+  int nts = 0;
+  const bool stamp = (ablate & 32) && blockIdx.x == gridDim.x / 2 && tid == 0;
+#define GANET_STAMP() do { if (stamp && nts < 80) ts[nts++] = wall_clock64(); } while (0)
+#else
+#define GANET_STAMP() do {} while (0)
+#endif
+  GANET_STAMP();
   load_b(0);
   load_a(0);
   store_b(0);
+#ifdef GANET_ABLATE
+  if (ablate & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  GANET_STAMP();
 
-  f32x16 acc;
-  for (int it = 0; it < total; ++it) {
-    const int n = it / kchunks, kc = it - n * kchunks;
-    const bool more = it + 1 < total;
-    __syncthreads();  // slice `it` is in its buffer; the other buffer is free again
-    if (more) load_b(it + 1);
-    if (kchunks > 1 && it > 0) load_a(kc);
-    if (kc == 0) {
+  f32x16 acc0, acc1;
+  // slice n into `acc`; `prev` (slice n-1, when flush) leaves during the first K chunk
+  auto slice = [&](int n, f32x16 &acc, const f32x16 &prev, bool flush) {
+    for (int kc = 0; kc < kchunks; ++kc) {
+      const int it = n * kchunks + kc;
+      const bool more = it + 1 < total;
+      __syncthreads();  // slice `it` is in its buffer; the other buffer is free again
+      GANET_STAMP();
+      if (more) load_b(it + 1);
+      if (kchunks > 1 && it > 0) load_a(kc);
+      if (kc == 0) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    }
-    {
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      }
+      const bool out_prev = flush && kc == 0;
       const unsigned char *Bs = s_b + (it & 1) * B_BYTES;
       const bf16_t *bh = reinterpret_cast<const bf16_t *>(Bs) + i * LDB + h * EPL;
       const bf16_t *bl = reinterpret_cast<const bf16_t *>(Bs + P_BYTES) + i * LDB + h * EPL;
@@ -359,39 +416,50 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_split_kernel(
       for (int q = 0; q < NQ; ++q) {
         const bf16x8 fh = *reinterpret_cast<const bf16x8 *>(bh + q * 16);
         const bf16x8 fl = *reinterpret_cast<const bf16x8 *>(bl + q * 16);
+#ifdef GANET_ABLATE  // profiling build only: bit0 skips the MFMAs, operands stay live
+        if (ablate & 1) {
+          asm volatile("" ::"v"(fa_hi[q]), "v"(fa_lo[q]), "v"(fh), "v"(fl));
+          continue;
+        }
+#endif
         // rows = outputs, columns = pixels; small terms first
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, fa_hi[q], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fa_lo[q], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fa_hi[q], acc, 0, 0, 0);
+        if (q == 0 && out_prev) stage_write(prev);
+        if (q == (NQ > 1 ? 1 : 0) && out_prev) stage_store(n - 1);
       }
+      GANET_STAMP();
+      if (more) store_b((it + 1) & 1);
+      GANET_STAMP();
     }
-    if (more) store_b((it + 1) & 1);
-    if (kc == kchunks - 1) {
-      // lane (i, h), registers 4g..4g+3 hold outputs 8g + 4h + 0..3 of pixel i
-      unsigned char *ys = s_y + wid * 32 * YROW;
-      float *yr = reinterpret_cast<float *>(ys + i * YROW) + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        *reinterpret_cast<f32x4 *>(yr + 8 * g) = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int pc = lane & 7, rq = lane >> 3;   // 8 lanes x 16 B per 32-float row
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int rr = ps * 8 + rq;
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
-        const long long mr = m0 + rr;
-        if (mr < M)
-          *reinterpret_cast<u32x4 *>(y + mr * N + (size_t)n * SB + pc * 4) = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+  };
+#ifdef GANET_ABLATE
+  const bool all_stores = !(ablate & 4);   // bit2: keep only the last slice's stores
+#else
+  constexpr bool all_stores = true;
+#endif
+  int n = 0;
+  for (; n + 1 < nslices; n += 2) {
+    slice(n, acc0, acc1, n > 0 && all_stores);
+    slice(n + 1, acc1, acc0, all_stores);
   }
+  if (n < nslices) {
+    slice(n, acc0, acc1, n > 0 && all_stores);
+    stage_write(acc0);
+  } else {
+    stage_write(acc1);
+  }
+  stage_store(nslices - 1);
+  GANET_STAMP();
+#ifdef GANET_ABLATE
+  if (stamp) {
+    printf("split gemm stamps (10 ns units, block %d):", (int)blockIdx.x);
+    for (int j = 1; j < nts; ++j) printf(" %d", (int)(ts[j] - ts[0]));
+    printf("\n");
+  }
+#endif
+#undef GANET_STAMP
 }
 
 // ---- out = sum over taps of bilinear samples of Y -----------------------------------
@@ -668,7 +736,7 @@ void launch_gemm(int kh, const void *x, const void *wq, void *y, long long M, in
 }
 
 void launch_gemm_split(const void *x, const void *wq, void *y, long long M, int Cp, int N,
-                       hipStream_t s) {
+                       int ablate, hipStream_t s) {
   constexpr int ROWS = GEMM_WAVES * 32;
   const unsigned gx = (unsigned)((M + ROWS - 1) / ROWS);
   const int nslices = N / 32;
@@ -682,11 +750,11 @@ void launch_gemm_split(const void *x, const void *wq, void *y, long long M, int 
   const bf16_t *ww = static_cast<const bf16_t *>(wq);
   float *yy = static_cast<float *>(y);
   if (Cp % 256 == 0)
-    hipLaunchKernelGGL((cts_gemm_split_kernel<256>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+    hipLaunchKernelGGL((cts_gemm_split_kernel<256>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per, ablate);
   else if (Cp % 128 == 0)
-    hipLaunchKernelGGL((cts_gemm_split_kernel<128>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+    hipLaunchKernelGGL((cts_gemm_split_kernel<128>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per, ablate);
   else
-    hipLaunchKernelGGL((cts_gemm_split_kernel<64>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+    hipLaunchKernelGGL((cts_gemm_split_kernel<64>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per, ablate);
 }
 
 template <typename TY, typename TO>
@@ -760,7 +828,7 @@ int cts_forward(const void *xh, const float *offset, const float *mask, const vo
     const unsigned char *xc =
         static_cast<const unsigned char *>(xh) + (size_t)img0 * p->H * p->W * Cp * es;
     if (split)
-      launch_gemm_split(xc, wq, ybuf, M, Cp, N, s);
+      launch_gemm_split(xc, wq, ybuf, M, Cp, N, p->debug, s);
     else if (ta == GANET_F32)
       launch_gemm<float, float>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
     else if (ta == GANET_BF16)

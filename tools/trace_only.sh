@@ -1,0 +1,14 @@
+#!/bin/bash
+# kernel-trace stats only: tools/trace_only.sh <tag> [bench args...]
+TAG=$1; shift
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/trace_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o t -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > "$OUT/log.txt" 2>&1 || { tail -5 "$OUT/log.txt"; exit 1; }
+python3 - "$OUT" <<'PY'
+import csv,glob,sys
+f=glob.glob(sys.argv[1]+"/**/*kernel_stats.csv",recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:8]:
+    print("%-60s calls %5s avg_us %9.1f pct %5s" % (r["Name"][:60], r["Calls"], float(r["AverageNs"])/1e3, r["Percentage"]))
+PY
