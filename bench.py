@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture one step in a HIP graph and replay it (small batches: "
                          "removes the host launch cost)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="LFA and decode on one stream (default: decode/grouping/pack run on "
+                         "a stream of their own beside the LFA - they do not depend on it)")
     ap.add_argument("--overlap-copy", action="store_true",
                     help="copy the lane lists D2H on a second stream")
     args = ap.parse_args()
@@ -201,17 +204,37 @@ def main():
                  max_kpts=min(H * W, 4096 if cfg["lanes"] > 4 else 1024),
                  max_centers=256, overlap_copy=args.overlap_copy,
                  mfma_bf16={"auto": 0, "bf16": 1, "exact": 2}[args.fp32_mode],
+                 side_decode=wl["decode"] and not (args.single_stream or args.graph
+                                                   or args.overlap_copy),
                  ablate=args.ablate, algo=args.algo, pack_to_host=not args.device_pack)
     if args.pts == "zero":
         d["pts"].zero_()
     hp.set_weight(d["w"])
 
     def one_step(ev=None):
+        if hp.side is not None:
+            # two streams: the LFA on the current one, decode beside it (HotPath.step)
+            cur = torch.cuda.current_stream(dev)
+            hp.inputs_ready.record(cur)
+            if ev is not None:
+                ev[0].record()
+            hp.lfa(d["x"], d["pts"])
+            if ev is not None:
+                ev[1].record()
+            with torch.cuda.stream(hp.side):
+                hp.side.wait_event(hp.inputs_ready)
+                if ev is not None:
+                    ev[3].record()
+                hp.decode(d["heat"], d["off"], d["err"])
+                if ev is not None:
+                    ev[2].record()
+            return
         if ev is not None:
             ev[0].record()
         hp.lfa(d["x"], d["pts"])
         if ev is not None:
             ev[1].record()
+            ev[3].record()
         if wl["decode"]:
             hp.decode(d["heat"], d["off"], d["err"])
             if ev is not None:
@@ -239,7 +262,7 @@ def main():
         if over:
             raise SystemExit("decode capacity overflow in the bench configuration")
 
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)]
               for _ in range(args.steps)]
     if dist is not None:
         dist.barrier()
@@ -266,7 +289,7 @@ def main():
             one_step(events[i])
         torch.cuda.synchronize()
     lfa_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if wl["decode"] else 0.0
+    dec_ms = float(np.mean([e[3].elapsed_time(e[2]) for e in events])) if wl["decode"] else 0.0
 
     if rank == 0:
         nbytes, flops = lfa_algorithmic(B, Cin, 64, H, W, K, dtype)
@@ -330,6 +353,8 @@ def main():
                        "layout": "NHWC (channels_last) resident in HBM",
                        "fp32_mode": args.fp32_mode if dtype == "fp32" else None,
                        "launch": "hip graph replay" if graph is not None else "eager",
+                       "streams": ("LFA and decode on two streams" if hp.side is not None
+                                   else "one stream"),
                        "parallelism": "image-sharded x%d, no collective" % world},
             "roofline": roof,
             "lfa_ms": lfa_ms,

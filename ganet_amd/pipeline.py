@@ -27,7 +27,8 @@ class HotPath(object):
                  by_center_thr=5.0, max_kpts=1024, max_centers=128,
                  channels_last=True, mfma_bf16=False, fuse_relu=True,
                  offset_is_points=True, expect_kpts=192, expect_centers=16,
-                 overlap_copy=False, ablate=0, algo=0, pack_to_host=True):
+                 overlap_copy=False, ablate=0, algo=0, pack_to_host=True,
+                 side_decode=False):
         self.L = _lib.lib()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.B, self.H, self.W, self.K = B, H, W, K
@@ -87,6 +88,12 @@ class HotPath(object):
             self.dws = torch.empty(max(self.dws_bytes, 256), dtype=torch.uint8,
                                    device=self.device)
             self.overlap_copy = overlap_copy
+            # side_decode: decode + grouping + pack go to a stream of their own.  They do
+            # not depend on the LFA of the same step, are latency-bound (a few dozen
+            # workgroups) and slot into the LFA kernels' ramps and tails instead of
+            # extending the step.
+            self.side = torch.cuda.Stream(device=self.device) if side_decode else None
+            self.inputs_ready = torch.cuda.Event() if side_decode else None
             self.pack_to_host = pack_to_host and not overlap_copy
             self.copy_stream = (torch.cuda.Stream(device=self.device) if overlap_copy
                                 else None)
@@ -158,8 +165,17 @@ class HotPath(object):
         self.cur ^= 1
 
     def step(self, x, pts, heat, offset, error):
+        if self.side is None:
+            self.lfa(x, pts)
+            self.decode(heat, offset, error)
+            return
+        # the step's inputs are ready where the current stream stands now
+        cur = torch.cuda.current_stream(self.device)
+        self.inputs_ready.record(cur)
         self.lfa(x, pts)
-        self.decode(heat, offset, error)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.inputs_ready)
+            self.decode(heat, offset, error)
 
     def capture(self, x, pts, heat, offset, error):
         """Record one step on these (fixed) input tensors into a HIP graph and return
@@ -167,7 +183,7 @@ class HotPath(object):
         the host launch cost is a quarter of the step).  The step allocates nothing and
         never synchronises, so it captures as it stands; `result()` works after a replay
         as after `step()`."""
-        assert not self.overlap_copy, "capture needs the single-stream flow"
+        assert not self.overlap_copy and self.side is None, "capture needs the single-stream flow"
         cur = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(cur)
@@ -188,6 +204,8 @@ class HotPath(object):
         torch.cuda.current_stream(self.device).synchronize()
         if self.copy_stream is not None:
             self.copy_stream.synchronize()
+        if self.side is not None:
+            self.side.synchronize()
         slot = self.last
         bufs, host = slot["bufs"], slot["host"].numpy()
         total = bufs.header_words + int(host[6])

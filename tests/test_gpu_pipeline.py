@@ -93,3 +93,31 @@ def test_pack_paths_and_graph_replay_agree():
     assert np.array_equal(r_g2.header, r_d2.header)
     assert np.array_equal(r_g2.records, r_d2.records)
     assert int(r_g2.header[:, 0].sum()) < int(r_host.header[:, 0].sum())
+
+
+def test_decode_beside_the_lfa_on_a_second_stream():
+    """side_decode: decode/grouping/pack run on a stream of their own; several steps back to
+    back (the streams drift apart) must still give the one-stream result, also when the
+    inputs of a later step were produced on the current stream just before it."""
+    B = 7
+    hp, d = build(B, torch.bfloat16)
+    hp.step(d["x"], d["pts"], d["heat"], d["off"], d["err"])
+    r1 = hp.result()
+    feat = hp.feature.clone()
+    hs, _ = build(B, torch.bfloat16, side_decode=True)
+    for _ in range(5):
+        hs.step(d["x"], d["pts"], d["heat"], d["off"], d["err"])
+    rs = hs.result()
+    assert np.array_equal(r1.header, rs.header)
+    assert np.array_equal(r1.records, rs.records)
+    torch.cuda.synchronize()
+    assert torch.equal(hs.feature, feat)
+    check_decode(rs, d, B)
+    heat2 = d["heat"] * 0.45          # produced on the current stream, consumed on the side one
+    hs.step(d["x"], d["pts"], heat2, d["off"], d["err"])
+    r2s = hs.result()
+    hp.step(d["x"], d["pts"], heat2, d["off"], d["err"])
+    r2 = hp.result()
+    assert np.array_equal(r2.header, r2s.header)
+    assert np.array_equal(r2.records, r2s.records)
+    assert int(r2.header[:, 0].sum()) < int(r1.header[:, 0].sum())
