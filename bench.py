@@ -312,7 +312,10 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("%s_%s" % (args.workload, dtype))
+                key = "%s_%s" % (args.workload, dtype)
+                if dtype == "fp32" and args.fp32_mode != "auto":
+                    key += "_" + args.fp32_mode
+                traffic = json.load(open(tfile)).get(key)
             except Exception:
                 traffic = None
         if t_mfma >= t_hbm:
