@@ -178,14 +178,22 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    # rehearsal knobs (one-GPU box): GANET_BENCH_DEVICE pins every rank to one device,
+    # GANET_BENCH_BACKEND=gloo replaces RCCL for the barrier / max-over-ranks
+    if os.environ.get("GANET_BENCH_DEVICE"):
+        local_rank = int(os.environ["GANET_BENCH_DEVICE"])
+    backend = os.environ.get("GANET_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from ganet_amd import _lib
     from ganet_amd.pipeline import HotPath
@@ -278,7 +286,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu",
+                         dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
