@@ -40,18 +40,28 @@ constexpr int kFusedMaskWords = 128;  // images up to 8192 pixels: bitmap formed
 
 // heat * (max_pool2d(heat,(1,3),1,(0,1)) == heat)   ganet_head.py:205-208.
 // ATen's pool starts at -inf and takes v when (v > max) || isnan(v).
-__device__ __forceinline__ float heat_nms(const float *__restrict__ row, int W,
-                                          int x) {
-  const float h = row[x];
+// rows3: the north star's 3x3 window (max_pool2d(heat,(3,3),1,(1,1)), walked row-major
+// like ATen); the reference always runs 1x3.  `img` is the image's first row.
+__device__ __forceinline__ float heat_nms(const float *__restrict__ img, int H, int W,
+                                          int y, int x, bool rows3) {
+  const float h = img[y * W + x];
   float m = -INFINITY;
-  if (x > 0) {
-    const float v = row[x - 1];
-    if (v > m || v != v) m = v;
-  }
-  if (h > m || h != h) m = h;
-  if (x < W - 1) {
-    const float v = row[x + 1];
-    if (v > m || v != v) m = v;
+  const int y0 = rows3 && y > 0 ? y - 1 : y;
+  const int y1 = rows3 && y < H - 1 ? y + 1 : y;
+  for (int yy = y0; yy <= y1; ++yy) {
+    const float *row = img + yy * W;
+    if (x > 0) {
+      const float v = row[x - 1];
+      if (v > m || v != v) m = v;
+    }
+    {
+      const float v = row[x];
+      if (v > m || v != v) m = v;
+    }
+    if (x < W - 1) {
+      const float v = row[x + 1];
+      if (v > m || v != v) m = v;
+    }
   }
   const float keep = (m == h) ? 1.0f : 0.0f;
   return h * keep;
@@ -59,14 +69,14 @@ __device__ __forceinline__ float heat_nms(const float *__restrict__ row, int W,
 
 __global__ __launch_bounds__(kBlock) void decode_mask_kernel(
     const float *__restrict__ heat, int HW, int W, float thr,
-    unsigned long long *__restrict__ kmask, int nwords) {
+    unsigned long long *__restrict__ kmask, int nwords, int rows3) {
   const int b = blockIdx.y;
   const int idx = blockIdx.x * kBlock + threadIdx.x;
   bool is_kpt = false;
   if (idx < HW) {
     const int y = idx / W;
     const int x = idx - y * W;
-    is_kpt = heat_nms(heat + (size_t)b * HW + (size_t)y * W, W, x) > thr;
+    is_kpt = heat_nms(heat + (size_t)b * HW, HW / W, W, y, x, rows3 != 0) > thr;
   }
   const unsigned long long m = __ballot(is_kpt);
   const int word = idx >> 6;
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       if (idx < (int)HW) {
         const int y = idx / W;
         const int x = idx - y * W;
-        is_kpt = heat_nms(s_heat + y * W, W, x) > a.kpt_thr;
+        is_kpt = heat_nms(s_heat, a.H, W, y, x, (a.flags & 2) != 0) > a.kpt_thr;
       }
       const unsigned long long m = __ballot(is_kpt);
       if (lane == 0 && (idx >> 6) < a.nwords) s_mask[idx >> 6] = m;
@@ -362,17 +372,22 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       }
     }
     __syncthreads();
-    // ---- 5. keypoint -> first centre within thr (post_process.py:61-66,173-179)
+    // ---- 5. keypoint -> first centre within thr (post_process.py:61-66,173-179);
+    //         flags bit2: the north star's variant, the NEAREST centre within thr
+    //         (ties to the lower group index)
+    const bool nearest = (a.flags & 4) != 0;
     for (int i = tid; i < nk_st; i += kBlock) {
       const double rx = (double)o_root[2 * i], ry = (double)o_root[2 * i + 1];
       int found = -1;
+      double best = 0;
       for (int g = 0; g < ng; ++g) {
         const double dx = rx - (double)gsumx[g];
         const double dy = ry - (double)gsumy[g];
         const double d = sqrt(dx * dx + dy * dy);
-        if (d <= T) {
+        if (d <= T && (found < 0 || d < best)) {
           found = g;
-          break;
+          best = d;
+          if (!nearest) break;
         }
       }
       o_kgid[i] = found;
@@ -561,7 +576,7 @@ extern "C" int ganet_decode_batch(const float *heat, const float *offset,
   if (!fused_mask) {
     dim3 g1((HW + kBlock - 1) / kBlock, p->B);
     hipLaunchKernelGGL(decode_mask_kernel, g1, dim3(kBlock), 0, s, heat, HW,
-                       p->W, p->kpt_thr, kmask, nwords);
+                       p->W, p->kpt_thr, kmask, nwords, p->flags & 2);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
 

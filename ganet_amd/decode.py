@@ -157,10 +157,18 @@ def _params(B, H, W, thr, root_thr, cluster_thr, by_center_thr, caps, flags=0):
     return p
 
 
+FLAG_NO_GROUP, FLAG_NMS_3X3, FLAG_NEAREST = 1, 2, 4
+
+
 def decode_batch(heat, offset, error, thr=0.1, root_thr=1, cluster_thr=4,
                  cluster_by_center_thr=None, group=True, max_kpts=None,
-                 max_centers=None, max_groups=None, keep_device=False):
+                 max_centers=None, max_groups=None, keep_device=False,
+                 nms_3x3=False, assign_nearest=False):
     """Decode (and group) a batch on the GPU.
+
+    nms_3x3 / assign_nearest: non-default variants with no counterpart in the
+    reference's code (3x3 heat-map NMS instead of its 1x3, nearest centre within the
+    threshold instead of the first one) - the forms BASELINE.json's north star names.
 
     heat [B,1,H,W], offset [B,2,H,W], error [B,2,H,W]: float32 CUDA tensors.
     Returns a DecodeResult (host arrays after one D2H copy).  Capacities grow
@@ -179,7 +187,9 @@ def decode_batch(heat, offset, error, thr=0.1, root_thr=1, cluster_thr=4,
     caps = _default_caps(H, W, by_center, max_kpts, max_centers, max_groups)
     while True:
         p = _params(B, H, W, thr, root_thr, cluster_thr, cluster_by_center_thr,
-                    caps, flags=0 if group else 1)
+                    caps, flags=(0 if group else FLAG_NO_GROUP) |
+                    (FLAG_NMS_3X3 if nms_3x3 else 0) |
+                    (FLAG_NEAREST if assign_nearest else 0))
         with torch.cuda.device(heat.device):
             bufs = DecodeBuffers(B, caps[0], caps[1], caps[2], heat.device)
             ws_bytes = L.ganet_decode_workspace_bytes(ctypes.byref(p))

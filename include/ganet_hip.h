@@ -194,7 +194,15 @@ typedef struct {
   int32_t max_kpts;     /* capacity of the per-image keypoint arrays */
   int32_t max_centers;  /* capacity of the per-image centre arrays (<= 2048) */
   int32_t max_groups;   /* capacity of the per-image group arrays */
-  int32_t flags;        /* bit0: skip grouping (decode only) */
+  int32_t flags;        /* bit0: skip grouping (decode only).
+                           The reference's behaviour is flags bits 1-2 = 0; the two
+                           variants below have no counterpart in its code (they are the
+                           forms its paper / BASELINE.json's north star describe):
+                           bit1: 3x3 heat-map NMS, max_pool2d(heat,(3,3),1,(1,1)),
+                                 instead of the reference's 1x3 (ganet_head.py:205-208);
+                           bit2: a keypoint joins the NEAREST group centre within the
+                                 threshold (ties: lower index) instead of the first
+                                 one (post_process.py:61-66) */
   int32_t reserved[4];
 } ganet_decode_params;
 

@@ -43,6 +43,16 @@ def lib():
             _f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
             ctypes.c_float, _i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
             _i32p, _f32p, _f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.oracle_decode_opt.restype = ctypes.c_int
+        L.oracle_decode_opt.argtypes = [
+            _f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+            ctypes.c_float, ctypes.c_int, _i64p, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int), _i32p, _f32p, _f32p, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int)]
+        L.oracle_group_fast_opt.restype = ctypes.c_int
+        L.oracle_group_fast_opt.argtypes = [
+            _i64p, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_double,
+            ctypes.c_double, ctypes.c_int, _i32p, _i64p, _i32p]
         L.oracle_group_fast.restype = ctypes.c_int
         L.oracle_group_fast.argtypes = [
             _i64p, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_double,
@@ -123,8 +133,9 @@ def deform_conv_backward(x, offset, weight, grad_out, stride=(1, 1), padding=(0,
     return out
 
 
-def decode(heat, offset, error, thr, root_thr=1.0):
+def decode(heat, offset, error, thr, root_thr=1.0, nms_rows=1):
     """One image.  heat [H,W] (or [1,1,H,W]), offset/error [2,H,W].
+    nms_rows = 3: the north star's 3x3 NMS variant (the reference runs 1x3).
     Returns centers int64 [Nc,2] (x,y; x-major), kpt_xy int32 [N,2],
     align f32 [N,2], root f32 [N,2] (row-major keypoint order)."""
     heat = _f32(heat).reshape(heat.shape[-2], heat.shape[-1])
@@ -137,27 +148,28 @@ def decode(heat, offset, error, thr, root_thr=1.0):
     align = np.zeros((cap, 2), np.float32)
     root = np.zeros((cap, 2), np.float32)
     nc, nk = ctypes.c_int(0), ctypes.c_int(0)
-    lib().oracle_decode(_p(heat, _f32p), _p(offset, _f32p), _p(error, _f32p),
-                        H, W, float(thr), float(root_thr), _p(centers, _i64p),
-                        cap, ctypes.byref(nc), _p(kxy, _i32p), _p(align, _f32p),
-                        _p(root, _f32p), cap, ctypes.byref(nk))
+    lib().oracle_decode_opt(_p(heat, _f32p), _p(offset, _f32p), _p(error, _f32p),
+                            H, W, float(thr), float(root_thr), int(nms_rows),
+                            _p(centers, _i64p), cap, ctypes.byref(nc), _p(kxy, _i32p),
+                            _p(align, _f32p), _p(root, _f32p), cap, ctypes.byref(nk))
     nc, nk = nc.value, nk.value
     return (centers[:nc].copy(), kxy[:nk].copy(), align[:nk].copy(),
             root[:nk].copy())
 
 
-def group_fast(centers, root, thr, by_center_thr):
+def group_fast(centers, root, thr, by_center_thr, nearest=False):
     """group_points_fast.  Returns (kpt_gid int32[N], group_mean int64[G,2],
-    center_gid int32[Nc], n_groups)."""
+    center_gid int32[Nc], n_groups).  nearest: the north star's nearest-centre variant
+    (the reference takes the first centre within the threshold)."""
     centers = np.ascontiguousarray(centers, dtype=np.int64).reshape(-1, 2)
     root = _f32(root).reshape(-1, 2)
     nc, nk = len(centers), len(root)
     cg = np.full(max(nc, 1), -1, np.int32)
     kg = np.full(max(nk, 1), -1, np.int32)
     gm = np.zeros((max(nc, nk, 1), 2), np.int64)
-    ng = lib().oracle_group_fast(
+    ng = lib().oracle_group_fast_opt(
         _p(centers, _i64p), nc, _p(root, _f32p), nk, float(thr),
-        -1.0 if by_center_thr is None else float(by_center_thr),
+        -1.0 if by_center_thr is None else float(by_center_thr), 1 if nearest else 0,
         _p(cg, _i32p), _p(gm, _i64p), _p(kg, _i32p))
     n_means = ng if by_center_thr is not None else 0
     return kg[:nk].copy(), gm[:n_means].copy(), cg[:nc].copy(), ng

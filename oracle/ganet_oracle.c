@@ -365,13 +365,20 @@ int oracle_deform_conv_backward(const float *x, const float *offset, const float
 
 /* heat * (max_pool2d(heat,(1,3),1,(0,1)) == heat)   (ganet_head.py:205-208).
  * ATen's CPU max-pool starts from -inf and takes `val` when
- * (val > max) || isnan(val), so a NaN in the window wins. */
-static float oracle_heat_nms(const float *heat, int W, int y, int x) {
+ * (val > max) || isnan(val), so a NaN in the window wins.
+ * nms_rows = 3 is the north star's 3x3 variant (max_pool2d(heat,(3,3),1,(1,1)),
+ * window walked row-major as ATen does); the reference always runs 1x3. */
+static float oracle_heat_nms(const float *heat, int H, int W, int y, int x,
+                             int nms_rows) {
   float m = -INFINITY;
-  for (int xx = x - 1; xx <= x + 1; ++xx) {
-    if (xx < 0 || xx >= W) continue;
-    float v = heat[(size_t)y * W + xx];
-    if (v > m || isnan(v)) m = v;
+  const int r = nms_rows == 3 ? 1 : 0;
+  for (int yy = y - r; yy <= y + r; ++yy) {
+    if (yy < 0 || yy >= H) continue;
+    for (int xx = x - 1; xx <= x + 1; ++xx) {
+      if (xx < 0 || xx >= W) continue;
+      float v = heat[(size_t)yy * W + xx];
+      if (v > m || isnan(v)) m = v;
+    }
   }
   float h = heat[(size_t)y * W + x];
   float keep = (m == h) ? 1.0f : 0.0f;
@@ -386,16 +393,16 @@ static float oracle_heat_nms(const float *heat, int W, int y, int x) {
  *   root[n_k][2]     float (x+off_x, y+off_y)      (ganet_head.py:229,232)
  * thr and root_thr are compared in float32, as torch does for a Python
  * scalar against a float32 tensor. */
-int oracle_decode(const float *heat, const float *offset, const float *error,
-                  int H, int W, float thr, float root_thr, int64_t *centers,
-                  int cap_c, int *n_c, int32_t *kpt_xy, float *align,
-                  float *root, int cap_k, int *n_k) {
+int oracle_decode_opt(const float *heat, const float *offset, const float *error,
+                      int H, int W, float thr, float root_thr, int nms_rows,
+                      int64_t *centers, int cap_c, int *n_c, int32_t *kpt_xy,
+                      float *align, float *root, int cap_k, int *n_k) {
   const size_t HW = (size_t)H * W;
   int nc = 0, nk = 0;
   /* centres: mask transposed to [W,H] before np.where -> x-major */
   for (int x = 0; x < W; ++x)
     for (int y = 0; y < H; ++y) {
-      float v = oracle_heat_nms(heat, W, y, x);
+      float v = oracle_heat_nms(heat, H, W, y, x, nms_rows);
       if ((offset[HW + (size_t)y * W + x] < root_thr) && (v > thr)) {
         if (nc < cap_c) {
           centers[2 * nc] = x;
@@ -407,7 +414,7 @@ int oracle_decode(const float *heat, const float *offset, const float *error,
   /* keypoints: torch.where on [H,W,2] -> row-major */
   for (int y = 0; y < H; ++y)
     for (int x = 0; x < W; ++x) {
-      float v = oracle_heat_nms(heat, W, y, x);
+      float v = oracle_heat_nms(heat, H, W, y, x, nms_rows);
       if (v > thr) {
         if (nk < cap_k) {
           size_t i = (size_t)y * W + x;
@@ -424,6 +431,15 @@ int oracle_decode(const float *heat, const float *offset, const float *error,
   *n_c = nc;
   *n_k = nk;
   return (nc > cap_c || nk > cap_k) ? 1 : 0;
+}
+
+/* the reference's decode: 1x3 NMS */
+int oracle_decode(const float *heat, const float *offset, const float *error,
+                  int H, int W, float thr, float root_thr, int64_t *centers,
+                  int cap_c, int *n_c, int32_t *kpt_xy, float *align,
+                  float *root, int cap_k, int *n_k) {
+  return oracle_decode_opt(heat, offset, error, H, W, thr, root_thr, 1, centers,
+                           cap_c, n_c, kpt_xy, align, root, cap_k, n_k);
 }
 
 /* ------------------------------------------------------------------------
@@ -450,10 +466,10 @@ static double oracle_dis_dd(double ax, double ay, double bx, double by) {
  *   group_mean[n_g][2]    int64 truncated mean (choose_mean_point :38-41)
  *   kpt_gid[nk]           group index of every keypoint, -1 = dropped
  * Returns the number of groups. */
-int oracle_group_fast(const int64_t *centers, int nc, const float *root,
-                      int nk, double thr, double by_center_thr,
-                      int32_t *center_gid, int64_t *group_mean,
-                      int32_t *kpt_gid) {
+int oracle_group_fast_opt(const int64_t *centers, int nc, const float *root,
+                          int nk, double thr, double by_center_thr, int nearest,
+                          int32_t *center_gid, int64_t *group_mean,
+                          int32_t *kpt_gid) {
   int ng = 0;
   if (by_center_thr >= 0) {
     const double T = by_center_thr;
@@ -482,16 +498,22 @@ int oracle_group_fast(const int64_t *centers, int nc, const float *root,
       group_mean[2 * g] = (int64_t)((double)sx / (double)cnt);
       group_mean[2 * g + 1] = (int64_t)((double)sy / (double)cnt);
     }
-    /* search_groups_by_centers (:61-66): first centre within thr */
+    /* search_groups_by_centers (:61-66): first centre within thr.
+     * nearest != 0 is the north star's variant: the NEAREST centre within thr
+     * (ties go to the lower group index); the reference always takes the first. */
     for (int i = 0; i < nk; ++i) {
       int found = -1;
-      for (int g = 0; g < ng; ++g)
-        if (oracle_dis_dd((double)root[2 * i], (double)root[2 * i + 1],
-                          (double)group_mean[2 * g],
-                          (double)group_mean[2 * g + 1]) <= T) {
+      double best = 0;
+      for (int g = 0; g < ng; ++g) {
+        const double d = oracle_dis_dd((double)root[2 * i], (double)root[2 * i + 1],
+                                       (double)group_mean[2 * g],
+                                       (double)group_mean[2 * g + 1]);
+        if (d <= T && (found < 0 || d < best)) {
           found = g;
-          break;
+          best = d;
+          if (!nearest) break;
         }
+      }
       kpt_gid[i] = found;
     }
   } else {
@@ -507,6 +529,15 @@ int oracle_group_fast(const int64_t *centers, int nc, const float *root,
     }
   }
   return ng;
+}
+
+/* the reference's grouping: first centre within thr */
+int oracle_group_fast(const int64_t *centers, int nc, const float *root,
+                      int nk, double thr, double by_center_thr,
+                      int32_t *center_gid, int64_t *group_mean,
+                      int32_t *kpt_gid) {
+  return oracle_group_fast_opt(centers, nc, root, nk, thr, by_center_thr, 0,
+                               center_gid, group_mean, kpt_gid);
 }
 
 /* Whole per-image decode + grouping over a batch, for the CPU baseline:
