@@ -3,7 +3,7 @@
 # an ARM is a quoted group of env settings ("A=1 B=2") and/or bench flags ("--side-decode");
 # "base" = nothing.  One discarded warm-up run, then the arms interleaved (rep outer, arm
 # inner): the first process on a fresh box runs several % slow.
-ARMS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do ARMS+=("$1"); shift; done; shift
+ARMS=(); PRE=${AB_PRE:-}; while [ $# -gt 0 ] && [ "$1" != "--" ]; do ARMS+=("$1"); shift; done; shift
 timeout -k 10 200 python bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" >/dev/null 2>&1
 for rep in 1 2 3; do
 for arm in "${ARMS[@]}"; do
