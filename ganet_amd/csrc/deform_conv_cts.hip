@@ -249,6 +249,182 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_kernel(
 #undef GANET_STAMP
 }
 
+// ---- Y = X * Wq^T, 16-bit operands, results leaving under the next slice's MFMAs -----
+// Same ownership as cts_gemm_kernel (a wavefront keeps the channels of RB x 32 pixels in
+// registers) with 32-column slices and two alternating accumulator sets: while slice n is
+// contracted, the finished 32x32 blocks of slice n-1 are converted, parked in the wave's
+// LDS rows and stored - the staging writes, row reads and global stores sit between the
+// MFMAs instead of behind them (in cts_gemm_kernel a slice costs 2.0 us of MFMAs plus
+// 1.9 us of staging, stores and barrier skew in sequence: profiles/r01_ablation.txt).
+// Stores are branch-free buffer stores (rows past M fall outside the window), so the
+// wait for the next weight slice does not wait for them.
+template <typename TA, typename TY, int KH, int RB>
+__global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_ov_kernel(
+    const TA *__restrict__ x, const TA *__restrict__ wq, TY *__restrict__ y,
+    long long M, int Cp, int N, int slices_per_block) {
+  static_assert(sizeof(TA) == 2 && sizeof(TY) == 2, "16-bit operands and results");
+  constexpr int EPL = 8;
+  constexpr int NQ = KH / 16;
+  constexpr int LDB = KH + EPL;               // +16 B: conflict-free ds_read_b128
+  constexpr int SB = 32;                      // output columns per slice
+  constexpr int B_BYTES = SB * LDB * 2;
+  constexpr int NT = GEMM_WAVES * 64;
+  constexpr int YROW = SB * 2 + 16;           // staged row of one 32x32 block (bytes)
+  static_assert(NQ >= 2 * RB, "one epilogue step per K fragment");
+  typedef typename Mma<TA>::frag frag_t;
+  __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * B_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char s_y[GEMM_WAVES * 32 * YROW];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const long long m0 = ((long long)blockIdx.x * GEMM_WAVES + wid) * (32 * RB);
+  const TA *xrow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const long long r = m0 + rb * 32 + i;
+    xrow[rb] = x + (r < M ? r : M - 1) * Cp + h * EPL;
+  }
+
+  // Cp == KH (one K chunk: the host picks cts_gemm_kernel otherwise)
+  const int slice0 = blockIdx.y * slices_per_block;
+  const int nslices = min(slices_per_block, N / SB - slice0);
+  if (nslices <= 0) return;
+  wq += (size_t)slice0 * SB * Cp;
+  y += (size_t)slice0 * SB;
+
+  constexpr int BPIECES = SB * (KH / EPL);    // 16-byte pieces per slice
+  constexpr int BPT = (BPIECES + NT - 1) / NT;
+  u32x4 breg[BPT];
+  auto load_b = [&](int n) {
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NT;
+      if (BPIECES % NT != 0 && q >= BPIECES) break;
+      const int r = q / (KH / EPL), pc = q - r * (KH / EPL);
+      breg[j] = ldg128(wq + ((size_t)(n * SB + r) * Cp + pc * EPL));
+    }
+  };
+  auto store_b = [&](int buf) {
+    TA *Bs = reinterpret_cast<TA *>(s_b + buf * B_BYTES);
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NT;
+      if (BPIECES % NT != 0 && q >= BPIECES) break;
+      const int r = q / (KH / EPL), pc = q - r * (KH / EPL);
+      *reinterpret_cast<u32x4 *>(Bs + r * LDB + pc * EPL) = breg[j];
+    }
+  };
+
+  frag_t fa[RB][NQ];
+  auto load_a = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        fa[rb][q] = __builtin_bit_cast(frag_t, ldg128(xrow[rb] + q * 2 * EPL));
+  };
+
+  unsigned char *ys = s_y + wid * 32 * YROW;
+  const __amdgpu_buffer_rsrc_t ydst = __builtin_amdgcn_make_buffer_rsrc(
+      y, 0, (int)(((size_t)M * N - (size_t)slice0 * SB) * 2), 0x00020000);
+  // lane (i, h), registers 4g..4g+3 hold outputs 8g + 4h + 0..3 of pixel i
+  auto stage_write = [&](const f32x16 &acc) {
+    TY *yr = reinterpret_cast<TY *>(ys + i * YROW) + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      TY v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = from_f32<TY>(acc[4 * g + e]);
+      unsigned long long pk;
+      __builtin_memcpy(&pk, v, 8);
+      *reinterpret_cast<unsigned long long *>(yr + 8 * g) = pk;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto stage_store = [&](int n, int rb) {
+    const int pc = lane & 3, rq = lane >> 2;   // 4 lanes x 16 B per 32-column row
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int rr = ps * 16 + rq;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
+      const long long mr = m0 + rb * 32 + rr;
+      const unsigned off = mr < M ? (unsigned)((mr * N + n * SB + pc * 8) * 2) : OOB_OFFSET;
+      __builtin_amdgcn_raw_buffer_store_b128(v, ydst, off, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  load_b(0);
+  load_a();
+  store_b(0);
+
+  f32x16 acc0[RB], acc1[RB];
+  // slice n into `acc`; `prev` (slice n-1, when FLUSH) leaves between its MFMAs.  FLUSH
+  // and MORE are compile-time so that every wait is a counted one: with a branch around
+  // the prefetch or the stores the compiler falls back to vmcnt(0) at the end of every
+  // slice, which waits for the stores just issued and undoes the overlap.
+  auto slice = [&](int n, f32x16 (&acc)[RB], const f32x16 (&prev)[RB], auto flush_c,
+                   auto more_c) {
+    constexpr bool FLUSH = decltype(flush_c)::value, MORE = decltype(more_c)::value;
+    __syncthreads();  // slice n is in its buffer; the other buffer is free again
+    if constexpr (MORE) load_b(n + 1);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+    const TA *brow = reinterpret_cast<const TA *>(s_b + (n & 1) * B_BYTES) + i * LDB + h * EPL;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const frag_t fb = *reinterpret_cast<const frag_t *>(brow + q * 2 * EPL);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        Mma<TA>::mma(fb, fa[rb][q], acc[rb]);   // rows = outputs, columns = pixels
+      if constexpr (FLUSH) {
+        if (q < 2 * RB) {
+          if (q % 2 == 0)
+            stage_write(prev[q / 2]);
+          else
+            stage_store(n - 1, q / 2);
+        }
+      }
+    }
+    if constexpr (MORE) store_b((n + 1) & 1);
+  };
+  auto flush_last = [&](const f32x16 (&acc)[RB]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      stage_write(acc[rb]);
+      stage_store(nslices - 1, rb);
+    }
+  };
+  constexpr std::true_type yes{};
+  constexpr std::false_type no{};
+  if (nslices == 1) {
+    slice(0, acc0, acc1, no, no);
+    flush_last(acc0);
+    return;
+  }
+  slice(0, acc0, acc1, no, yes);
+  int n = 1;
+  for (; n + 2 <= nslices - 1; n += 2) {   // n and n + 1 are both followed by another slice
+    slice(n, acc1, acc0, yes, yes);
+    slice(n + 1, acc0, acc1, yes, yes);
+  }
+  if (n == nslices - 1) {
+    slice(n, acc1, acc0, yes, no);
+    flush_last(acc1);
+  } else {
+    slice(n, acc1, acc0, yes, yes);
+    slice(n + 1, acc0, acc1, yes, no);
+    flush_last(acc0);
+  }
+}
+
 // ---- Y = X * Wq^T for float32 tensors, on the bf16 matrix cores in three passes ------
 // x [M][Cp] float32, wq = two bf16 planes [N][Cp] (high parts, then low parts), y [M][N]
 // float32.  Every float is split as v = hi + lo with hi = bf16(v), lo = bf16(v - hi)
@@ -735,6 +911,50 @@ void launch_gemm(int kh, const void *x, const void *wq, void *y, long long M, in
     launch_gemm_rb<TA, TY, 1>(kh, x, wq, y, M, Cp, N, ablate, s);
 }
 
+// 16-bit operands: the overlapped-epilogue kernel (GANET_CTS_GEMM=tile selects the
+// tile-per-slice kernel above, for A/B runs)
+template <typename TA, typename TY, int RB>
+void launch_gemm_ov_rb(int kh, const void *x, const void *wq, void *y, long long M, int Cp,
+                       int N, hipStream_t s) {
+  constexpr int ROWS = GEMM_WAVES * 32 * RB;
+  const unsigned gx = (unsigned)((M + ROWS - 1) / ROWS);
+  const int nslices = N / 32;
+  int ny = gx > 64 ? 1 : (int)((256 + gx - 1) / gx);
+  if (ny > nslices) ny = nslices;
+  const int per = (nslices + ny - 1) / ny;
+  ny = (nslices + per - 1) / per;
+  dim3 grid(gx, (unsigned)ny);
+  dim3 block(GEMM_WAVES * 64);
+  const TA *xx = static_cast<const TA *>(x);
+  const TA *ww = static_cast<const TA *>(wq);
+  TY *yy = static_cast<TY *>(y);
+  if (kh == 256)
+    hipLaunchKernelGGL((cts_gemm_ov_kernel<TA, TY, 256, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+  else if (kh == 128)
+    hipLaunchKernelGGL((cts_gemm_ov_kernel<TA, TY, 128, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+  else
+    hipLaunchKernelGGL((cts_gemm_ov_kernel<TA, TY, 64, RB>), grid, block, 0, s, xx, ww, yy, M, Cp, N, per);
+}
+
+bool gemm_overlapped() {
+  static const int v = [] {
+    const char *e = getenv("GANET_CTS_GEMM");
+    return (e && e[0] == 't') ? 0 : 1;
+  }();
+  return v != 0;
+}
+
+template <typename TA, typename TY>
+void launch_gemm16(int kh, const void *x, const void *wq, void *y, long long M, int Cp,
+                   int N, int ablate, hipStream_t s) {
+  if (!gemm_overlapped() || ablate || Cp != kh)
+    launch_gemm<TA, TY>(kh, x, wq, y, M, Cp, N, ablate, s);
+  else if (M >= 192ll * GEMM_WAVES * 64)
+    launch_gemm_ov_rb<TA, TY, 2>(kh, x, wq, y, M, Cp, N, s);
+  else
+    launch_gemm_ov_rb<TA, TY, 1>(kh, x, wq, y, M, Cp, N, s);
+}
+
 void launch_gemm_split(const void *x, const void *wq, void *y, long long M, int Cp, int N,
                        int ablate, hipStream_t s) {
   constexpr int ROWS = GEMM_WAVES * 32;
@@ -832,9 +1052,9 @@ int cts_forward(const void *xh, const float *offset, const float *mask, const vo
     else if (ta == GANET_F32)
       launch_gemm<float, float>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
     else if (ta == GANET_BF16)
-      launch_gemm<bf16_t, bf16_t>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
+      launch_gemm16<bf16_t, bf16_t>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
     else
-      launch_gemm<f16_t, f16_t>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
+      launch_gemm16<f16_t, f16_t>(kc, xc, wq, ybuf, M, Cp, N, p->debug, s);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
 
     SampleArgs a;
