@@ -336,7 +336,9 @@ def main():
                         unit="GB/s", frac=hbm_achieved / HBM_PEAK_GBS)
         kernels = ("dcn_fused_kernel" if hp.lfa_algorithm == 1 else
                    "%s + cts_sample_kernel (all chunk pairs of one LFA launch)"
-                   % ("cts_gemm_split_kernel" if split else "cts_gemm_kernel"))
+                   % ("cts_gemm_split_kernel" if split else
+                      "cts_gemm_ov_kernel" if dtype != "fp32" and Cin in (64, 128, 256)
+                      and os.environ.get("GANET_CTS_GEMM", "o")[0] != "t" else "cts_gemm_kernel"))
         roof.update(traffic=traffic, kernel=kernels, lfa_algorithm=hp.lfa_algorithm,
                     kernel_ms=lfa_ms, algorithmic_bytes=nbytes, algorithmic_flops=flops,
                     hbm_gbs=hbm_achieved, hbm_frac=hbm_achieved / HBM_PEAK_GBS,

@@ -10,7 +10,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("dcn_fused_kernel", "cts_gemm_split_kernel", "cts_gemm_kernel", "pack_weight_split_kernel", "cts_sample_kernel",
+    for key in ("dcn_fused_kernel", "cts_gemm_split_kernel", "cts_gemm_ov_kernel", "cts_gemm_kernel", "pack_weight_split_kernel", "cts_sample_kernel",
                 "decode_mask_kernel", "decode_group_kernel", "decode_pack_kernel",
                 "nchw_to_nhwc_kernel", "nhwc_repack_kernel", "pack_weight_kernel"):
         if key in name:
