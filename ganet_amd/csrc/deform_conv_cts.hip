@@ -269,11 +269,11 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_ov_kernel(
   constexpr int SB = 32;                      // output columns per slice
   constexpr int B_BYTES = SB * LDB * 2;
   constexpr int NT = GEMM_WAVES * 64;
-  constexpr int YROW = SB * 2 + 16;           // staged row of one 32x32 block (bytes)
+  constexpr int YROW = 2 * SB * 2 + 16;       // staged row of two slices' 32x32 blocks (bytes)
   static_assert(NQ >= 2 * RB, "one epilogue step per K fragment");
   typedef typename Mma<TA>::frag frag_t;
   __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * B_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char s_y[GEMM_WAVES * 32 * YROW];
+  __shared__ __attribute__((aligned(16))) unsigned char s_y[GEMM_WAVES * RB * 32 * YROW];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_ov_kernel(
   // Cp == KH (one K chunk: the host picks cts_gemm_kernel otherwise)
   const int slice0 = blockIdx.y * slices_per_block;
   const int nslices = min(slices_per_block, N / SB - slice0);
-  if (nslices <= 0) return;
+  if (nslices <= 0 || (nslices & 1)) return;
   wq += (size_t)slice0 * SB * Cp;
   y += (size_t)slice0 * SB;
 
@@ -325,12 +325,15 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_ov_kernel(
         fa[rb][q] = __builtin_bit_cast(frag_t, ldg128(xrow[rb] + q * 2 * EPL));
   };
 
-  unsigned char *ys = s_y + wid * 32 * YROW;
+  unsigned char *ys = s_y + wid * (RB * 32 * YROW);
   const __amdgpu_buffer_rsrc_t ydst = __builtin_amdgcn_make_buffer_rsrc(
       y, 0, (int)(((size_t)M * N - (size_t)slice0 * SB) * 2), 0x00020000);
+  // Two slices share a staged row: the even slice parks its 32 columns in the left half,
+  // the odd one in the right half, and the row leaves as one whole 128-byte line (halves
+  // stored a slice apart do not merge in L2: WRITE_SIZE 136 MB against 115 MB of Y).
   // lane (i, h), registers 4g..4g+3 hold outputs 8g + 4h + 0..3 of pixel i
-  auto stage_write = [&](const f32x16 &acc) {
-    TY *yr = reinterpret_cast<TY *>(ys + i * YROW) + 4 * h;
+  auto stage_write = [&](const f32x16 &acc, int rb, int half) {
+    TY *yr = reinterpret_cast<TY *>(ys + (rb * 32 + i) * YROW + half * (SB * 2)) + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       TY v[4];
@@ -344,14 +347,15 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_ov_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  auto stage_store = [&](int n, int rb) {
-    const int pc = lane & 3, rq = lane >> 2;   // 4 lanes x 16 B per 32-column row
+  // rows of slices n_even and n_even + 1
+  auto stage_store = [&](int n_even, int rb) {
+    const int pc = lane & 7, rq = lane >> 3;   // 8 lanes x 16 B per 64-column row
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int rr = ps * 16 + rq;
-      const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + rr * YROW + pc * 16);
+    for (int ps = 0; ps < 4; ++ps) {
+      const int rr = ps * 8 + rq;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + (rb * 32 + rr) * YROW + pc * 16);
       const long long mr = m0 + rb * 32 + rr;
-      const unsigned off = mr < M ? (unsigned)((mr * N + n * SB + pc * 8) * 2) : OOB_OFFSET;
+      const unsigned off = mr < M ? (unsigned)((mr * N + n_even * SB + pc * 8) * 2) : OOB_OFFSET;
       __builtin_amdgcn_raw_buffer_store_b128(v, ydst, off, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -363,14 +367,16 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_ov_kernel(
   load_a();
   store_b(0);
 
+  // even slices accumulate in acc0, odd ones in acc1
   f32x16 acc0[RB], acc1[RB];
   // slice n into `acc`; `prev` (slice n-1, when FLUSH) leaves between its MFMAs.  FLUSH
   // and MORE are compile-time so that every wait is a counted one: with a branch around
   // the prefetch or the stores the compiler falls back to vmcnt(0) at the end of every
   // slice, which waits for the stores just issued and undoes the overlap.
   auto slice = [&](int n, f32x16 (&acc)[RB], const f32x16 (&prev)[RB], auto flush_c,
-                   auto more_c) {
+                   auto more_c, auto odd_c) {
     constexpr bool FLUSH = decltype(flush_c)::value, MORE = decltype(more_c)::value;
+    constexpr bool ODD = decltype(odd_c)::value;   // n is odd: prev is an even slice
     __syncthreads();  // slice n is in its buffer; the other buffer is free again
     if constexpr (MORE) load_b(n + 1);
 #pragma unroll
@@ -387,41 +393,28 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_ov_kernel(
       if constexpr (FLUSH) {
         if (q < 2 * RB) {
           if (q % 2 == 0)
-            stage_write(prev[q / 2]);
-          else
-            stage_store(n - 1, q / 2);
+            stage_write(prev[q / 2], q / 2, ODD ? 0 : 1);
+          else if (!ODD)
+            stage_store(n - 2, q / 2);
         }
       }
     }
     if constexpr (MORE) store_b((n + 1) & 1);
   };
-  auto flush_last = [&](const f32x16 (&acc)[RB]) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      stage_write(acc[rb]);
-      stage_store(nslices - 1, rb);
-    }
-  };
   constexpr std::true_type yes{};
   constexpr std::false_type no{};
-  if (nslices == 1) {
-    slice(0, acc0, acc1, no, no);
-    flush_last(acc0);
-    return;
-  }
-  slice(0, acc0, acc1, no, yes);
+  // nslices is even (the host keeps slices_per_block even, N is a multiple of 64)
+  slice(0, acc0, acc1, no, yes, no);
   int n = 1;
   for (; n + 2 <= nslices - 1; n += 2) {   // n and n + 1 are both followed by another slice
-    slice(n, acc1, acc0, yes, yes);
-    slice(n + 1, acc0, acc1, yes, yes);
+    slice(n, acc1, acc0, yes, yes, yes);
+    slice(n + 1, acc0, acc1, yes, yes, no);
   }
-  if (n == nslices - 1) {
-    slice(n, acc1, acc0, yes, no);
-    flush_last(acc1);
-  } else {
-    slice(n, acc1, acc0, yes, yes);
-    slice(n + 1, acc0, acc1, yes, no);
-    flush_last(acc0);
+  slice(n, acc1, acc0, yes, no, yes);       // n == nslices - 1
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    stage_write(acc1[rb], rb, 1);
+    stage_store(nslices - 2, rb);
   }
 }
 
@@ -920,8 +913,9 @@ void launch_gemm_ov_rb(int kh, const void *x, const void *wq, void *y, long long
   const unsigned gx = (unsigned)((M + ROWS - 1) / ROWS);
   const int nslices = N / 32;
   int ny = gx > 64 ? 1 : (int)((256 + gx - 1) / gx);
-  if (ny > nslices) ny = nslices;
-  const int per = (nslices + ny - 1) / ny;
+  if (ny > nslices / 2) ny = nslices / 2;
+  int per = (nslices + ny - 1) / ny;
+  per += per & 1;   // slices leave in pairs (whole 128-byte lines)
   ny = (nslices + per - 1) / per;
   dim3 grid(gx, (unsigned)ny);
   dim3 block(GEMM_WAVES * 64);
