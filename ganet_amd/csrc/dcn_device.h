@@ -127,4 +127,12 @@ int cts_forward(const void *xh, const float *offset, const float *mask, const vo
                 const void *bias, void *out, const ganet_dcn_params *p, int ta, int kc,
                 int Cp, int CoutP, int Ho, int Wo, void *ybuf, hipStream_t s);
 
+// exact-float32 GEMM of the same file, for the backward (csrc/deform_conv_bwd.hip)
+int cts_gemm_f32(const float *x, const float *wq, float *y, long long M, int K, int N,
+                 hipStream_t s);
+// the same product in three bf16 passes over high/low splits (float32-class accuracy);
+// wq_split: two bf16 planes [N][K] (high parts, then low parts)
+int cts_gemm_f32_split(const float *x, const void *wq_split, float *y, long long M, int K,
+                       int N, hipStream_t s);
+
 }  // namespace ganet_dcn

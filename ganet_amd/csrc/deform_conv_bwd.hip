@@ -380,10 +380,252 @@ __global__ __launch_bounds__(256) void bwd_unpack_add_weight_kernel(
   }
 }
 
+// ===== commuted form: scatter / gather Cout-wide rows of the per-tap products ===========
+// With Y_t = X * W_t^T (the forward's contract-then-sample intermediate) the backward is
+//   grad_Y_t[q][o] += bilinear weight * mask * grad_out[p][o]        (scatter, atomics)
+//   grad_x          = grad_Y * Wq                                     (one GEMM)
+//   grad_Wq[n][c]   = sum_q grad_Y[q][n] * x[q][c]                    (one GEMM over pixels)
+//   grad_offset, grad_mask from sum_o grad_out[p][o] * Y_t[corner][o]
+// since sum_c grad_col[c] * x[corner][c] = sum_o grad_out[o] * Y_t[corner][o].  The rows
+// that move through atomics are Cout wide instead of Cin wide (4x fewer bytes at 256 -> 64),
+// which is what the direct kernels above are bound by.  Same arithmetic per term as
+// deformable_col2im / col2im_coord (deform_conv_cuda_kernel.cu:279-427).
+struct BwdCtsArgs {
+  const float *y;        // [nimg*H*W][N] per-tap products of this chunk (nullptr: no coordinate gradients)
+  float *gy;             // same shape, zeroed, accumulated into
+  const float *go;       // [B*Ho*Wo][Cout] channel-last grad_out (whole batch)
+  const float *offset;   // whole batch
+  const float *mask;     // whole batch or nullptr
+  float *goff;           // zeroed, accumulated into
+  float *gmask;          // zeroed, accumulated into, or nullptr
+  int img0, nimg;
+  int H, W, Ho, Wo, Cout, T;
+  int kW, pH, pW, dH, dW;
+};
+
+constexpr int CS_WAVES = 4;
+constexpr int CS_TAPS = 32;   // taps whose geometry sits in LDS at a time
+
+// 32 lanes per pixel, lane l owns channels l and l + 32 of one 64-channel block
+// (blockIdx.y): every atomic instruction then adds one whole 128-byte run per pixel - the
+// shape float atomics run at full rate on (16 lanes x 4 channels, 16-byte loads and four
+// scattered words per lane, ran the scatter 3x slower).  2 pixels per wavefront.
+__global__ __launch_bounds__(CS_WAVES * 64) void cts_bwd_sample_kernel(BwdCtsArgs a) {
+  __shared__ __attribute__((aligned(16))) int s_geo[CS_WAVES][2][CS_TAPS][8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pj = lane >> 5, l = lane & 31;
+  const int cb = blockIdx.y;
+  const int HWo = a.Ho * a.Wo;
+  const int N = a.T * a.Cout;
+  const long long P = (long long)a.nimg * HWo;
+  const long long ngroups = (P + 1) / 2;
+  const int c0 = cb * 64 + l;          // and c0 + 32; Cout is a multiple of 64 on this path
+
+  for (long long grp = (long long)blockIdx.x * CS_WAVES + wid; grp < ngroups;
+       grp += (long long)gridDim.x * CS_WAVES) {
+    const long long p = grp * 2 + pj;
+    const bool valid = p < P;
+    const int bl = valid ? (int)(p / HWo) : 0;
+    const int hw = valid ? (int)(p - (long long)bl * HWo) : 0;
+    const int ho = hw / a.Wo, wo = hw - ho * a.Wo;
+    const int b = a.img0 + bl;
+    float g0 = 0.f, g1 = 0.f;
+    if (valid) {
+      const float *gp = a.go + ((size_t)b * HWo + hw) * a.Cout + c0;
+      g0 = ldg_f32(gp);
+      g1 = ldg_f32(gp + 32);
+    }
+
+    for (int t0 = 0; t0 < a.T; t0 += CS_TAPS) {
+      const int nt = min(CS_TAPS, a.T - t0);
+      if (l < nt) {
+        const int t = t0 + l;
+        const int ti = t / a.kW, tj = t - ti * a.kW;
+        int c1 = -1, c2 = -1, c3 = -1, c4 = -1;
+        float lh = 0.f, lw = 0.f, m = 0.f;
+        if (valid) {
+          const float *op = a.offset + ((size_t)b * 2 * a.T + 2 * t) * HWo + hw;
+          const float h_im = (float)(ho - a.pH + ti * a.dH) + ldg_f32(op);
+          const float w_im = (float)(wo - a.pW + tj * a.dW) + ldg_f32(op + HWo);
+          m = a.mask ? ldg_f32(a.mask + ((size_t)b * a.T + t) * HWo + hw) : 1.f;
+          if (h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W) {
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            lh = h_im - (float)h_low;
+            lw = w_im - (float)w_low;
+            // float index of the corner's row of tap t inside the chunk's Y
+            const int base = ((bl * a.H + h_low) * a.W + w_low) * N + t * a.Cout;
+            const bool hl = h_low >= 0, hh = h_high <= a.H - 1;
+            const bool wl = w_low >= 0, wh = w_high <= a.W - 1;
+            if (hl && wl) c1 = base;
+            if (hl && wh) c2 = base + N;
+            if (hh && wl) c3 = base + a.W * N;
+            if (hh && wh) c4 = base + a.W * N + N;
+          }
+        }
+        int *e = s_geo[wid][pj][l];
+        *reinterpret_cast<int4 *>(e) = make_int4(c1, c2, c3, c4);
+        *reinterpret_cast<int4 *>(e + 4) =
+            make_int4(__float_as_int(lh), __float_as_int(lw), __float_as_int(m), 0);
+      }
+      wave_sync_lds();
+#pragma unroll 2
+      for (int tt = 0; tt < nt; ++tt) {
+        const int4 cx = *reinterpret_cast<const int4 *>(s_geo[wid][pj][tt]);
+        const int4 ge = *reinterpret_cast<const int4 *>(s_geo[wid][pj][tt] + 4);
+        const float lh = __int_as_float(ge.x), lw = __int_as_float(ge.y), m = __int_as_float(ge.z);
+        const float hh = 1.f - lh, hw_ = 1.f - lw;
+        const int t = t0 + tt;
+        if (a.y) {
+          float v1a = 0.f, v1b = 0.f, v2a = 0.f, v2b = 0.f, v3a = 0.f, v3b = 0.f, v4a = 0.f, v4b = 0.f;
+          if (cx.x >= 0) { v1a = ldg_f32(a.y + cx.x + c0); v1b = ldg_f32(a.y + cx.x + c0 + 32); }
+          if (cx.y >= 0) { v2a = ldg_f32(a.y + cx.y + c0); v2b = ldg_f32(a.y + cx.y + c0 + 32); }
+          if (cx.z >= 0) { v3a = ldg_f32(a.y + cx.z + c0); v3b = ldg_f32(a.y + cx.z + c0 + 32); }
+          if (cx.w >= 0) { v4a = ldg_f32(a.y + cx.w + c0); v4b = ldg_f32(a.y + cx.w + c0 + 32); }
+          // get_coordinate_weight, deform_conv_cuda_kernel.cu:146-188
+          float sh = g0 * (-hw_ * v1a - lw * v2a + hw_ * v3a + lw * v4a) +
+                     g1 * (-hw_ * v1b - lw * v2b + hw_ * v3b + lw * v4b);
+          float sw = g0 * (-hh * v1a + hh * v2a - lh * v3a + lh * v4a) +
+                     g1 * (-hh * v1b + hh * v2b - lh * v3b + lh * v4b);
+          float sm = g0 * (hh * hw_ * v1a + hh * lw * v2a + lh * hw_ * v3a + lh * lw * v4a) +
+                     g1 * (hh * hw_ * v1b + hh * lw * v2b + lh * hw_ * v3b + lh * lw * v4b);
+          sh = half_wave_sum(sh);
+          sw = half_wave_sum(sw);
+          if (a.gmask) sm = half_wave_sum(sm);
+          if (l == 0 && valid) {
+            float *q = a.goff + ((size_t)b * 2 * a.T + 2 * t) * HWo + hw;
+            unsafeAtomicAdd(q, m * sh);
+            unsafeAtomicAdd(q + HWo, m * sw);
+            if (a.gmask) unsafeAtomicAdd(a.gmask + ((size_t)b * a.T + t) * HWo + hw, sm);
+          }
+        }
+        if (valid) {
+          const float w1 = hh * hw_ * m, w2 = hh * lw * m, w3 = lh * hw_ * m, w4 = lh * lw * m;
+          if (cx.x >= 0) {
+            unsafeAtomicAdd(a.gy + cx.x + c0, w1 * g0);
+            unsafeAtomicAdd(a.gy + cx.x + c0 + 32, w1 * g1);
+          }
+          if (cx.y >= 0) {
+            unsafeAtomicAdd(a.gy + cx.y + c0, w2 * g0);
+            unsafeAtomicAdd(a.gy + cx.y + c0 + 32, w2 * g1);
+          }
+          if (cx.z >= 0) {
+            unsafeAtomicAdd(a.gy + cx.z + c0, w3 * g0);
+            unsafeAtomicAdd(a.gy + cx.z + c0 + 32, w3 * g1);
+          }
+          if (cx.w >= 0) {
+            unsafeAtomicAdd(a.gy + cx.w + c0, w4 * g0);
+            unsafeAtomicAdd(a.gy + cx.w + c0 + 32, w4 * g1);
+          }
+        }
+      }
+      wave_sync_lds();
+    }
+  }
+}
+
+// gw[n][c] += sum_q gy[q][n] * x[q][c]   (gy [M][N], x [M][Cp], gw [N][Cp]; N, Cp % 64 == 0)
+// blockIdx.x = (n block, c block) of 64 x 64, blockIdx.y = share of the pixels; the four
+// wavefronts of a workgroup split its pixels and meet in LDS before one atomic flush.
+__global__ __launch_bounds__(256) void cts_bwd_wgrad_kernel(const float *__restrict__ gy,
+                                                            const float *__restrict__ x,
+                                                            float *__restrict__ gw, long long M,
+                                                            int N, int Cp) {
+  __shared__ float s_d[64][65];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int ncb = Cp / 64;
+  const int bn = blockIdx.x / ncb, bc = blockIdx.x - bn * ncb;
+  for (int k = tid; k < 64 * 65; k += 256) (&s_d[0][0])[k] = 0.f;
+  __syncthreads();
+  // pixel pairs of this workgroup, dealt to its wavefronts in turn
+  const long long npairs = (M + 1) / 2;
+  const long long per = (npairs + gridDim.y - 1) / gridDim.y;
+  const long long m_beg = (long long)blockIdx.y * per;
+  const long long m_end = m_beg + per < npairs ? m_beg + per : npairs;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+  const float *gcol = gy + bn * 64 + i;
+  const float *xcol = x + bc * 64 + i;
+#pragma unroll 4
+  for (long long m = m_beg + wid; m < m_end; m += 4) {
+    const long long q = 2 * m + h;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (q < M) {
+      a0 = ldg_f32(gcol + q * N);
+      a1 = ldg_f32(gcol + q * N + 32);
+      b0 = ldg_f32(xcol + q * Cp);
+      b1 = ldg_f32(xcol + q * Cp + 32);
+    }
+    // D[n][c] += gy[q][n] * x[q][c], k = the pixel pair
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        unsafeAtomicAdd(&s_d[row][v * 32 + i], acc[u][v][r]);
+      }
+  __syncthreads();
+  for (int k = tid; k < 64 * 64; k += 256) {
+    const int row = k >> 6, col = k & 63;
+    unsafeAtomicAdd(gw + (size_t)(bn * 64 + row) * Cp + bc * 64 + col, s_d[row][col]);
+  }
+}
+
+// float32 matrix -> a high and a low bf16 plane (v = hi + lo up to 2^-18 |v|), the operand
+// form of cts_gemm_split_kernel
+__global__ __launch_bounds__(256) void bwd_split_rows_kernel(const float *__restrict__ src,
+                                                             unsigned short *__restrict__ dst,
+                                                             long long n) {
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n;
+       k += (long long)gridDim.x * 256) {
+    const float v = src[k];
+    const __bf16 hi = (__bf16)v;
+    const float hf = __uint_as_float(((unsigned)__builtin_bit_cast(unsigned short, hi)) << 16);
+    const __bf16 lo = (__bf16)(v - hf);
+    dst[k] = __builtin_bit_cast(unsigned short, hi);
+    dst[n + k] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+// dst[c][n] = src[n][c]
+__global__ __launch_bounds__(256) void bwd_transpose_kernel(const float *__restrict__ src,
+                                                            float *__restrict__ dst, int N,
+                                                            int Cp) {
+  const long long total = (long long)N * Cp;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
+       k += (long long)gridDim.x * 256) {
+    const int c = (int)(k / N), n = (int)(k - (long long)c * N);
+    dst[k] = src[(size_t)n * Cp + c];
+  }
+}
+
 struct BwdPlan {
   int Ho, Wo, T, Cp;
   bool copy_x, copy_go;
   size_t xh_bytes, gxh_bytes, go_bytes, wp_bytes, gwp_bytes;
+  // commuted form
+  bool commuted;
+  int nb;                 // images per chunk
+  size_t y_bytes, gy_bytes, gxc_bytes, wqt_bytes, wsp_bytes;
+  size_t total() const {
+    return xh_bytes + gxh_bytes + go_bytes + wp_bytes + gwp_bytes + y_bytes + gy_bytes +
+           gxc_bytes + wqt_bytes + wsp_bytes;
+  }
 };
 
 int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
@@ -418,6 +660,36 @@ int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
   pl->go_bytes = pl->copy_go ? ganet_align_up(npix_out * p->Cout * 4, 256) : 0;
   pl->wp_bytes = ganet_align_up((size_t)pl->T * p->Cout * pl->Cp * 4, 256);
   pl->gwp_bytes = pl->wp_bytes;
+  // The commuted form applies under the forward's contract-then-sample conditions (one
+  // deformable group, stride 1, Cout-wide rows at most half as wide as Cin-wide ones) and
+  // needs whole 64-blocks on both sides of its GEMMs; p->algo: 0 automatic, 1 direct,
+  // 2 commuted (GANET_ERR_UNSUPPORTED where it does not apply).
+  const bool can = dg == 1 && p->sH == 1 && p->sW == 1 && p->Cout % 64 == 0 &&
+                   pl->Cp % 64 == 0 && pl->T <= 64 &&
+                   (size_t)p->H * p->W * pl->T * p->Cout < 0x7fffffffull / 4;
+  if (p->algo == 2 && !can) return GANET_ERR_UNSUPPORTED;
+  pl->commuted = can && (p->algo == 2 || (p->algo == 0 && 2 * p->Cout <= pl->Cp));
+  pl->nb = 0;
+  pl->y_bytes = pl->gy_bytes = pl->gxc_bytes = pl->wqt_bytes = pl->wsp_bytes = 0;
+  if (pl->commuted) {
+    const size_t N = (size_t)pl->T * p->Cout;
+    const size_t per_img = (size_t)p->H * p->W * N * 4;
+    size_t nb = (96ull << 20) / per_img;     // Y and grad_Y of a chunk stay in the Infinity Cache
+    const size_t lim = (0x7fffffffull / 4) / ((size_t)p->H * p->W * N);   // 31-bit float indices
+    if (nb > lim) nb = lim;
+    if (nb < 1) nb = 1;
+    if (nb > (size_t)p->B) nb = p->B;
+    const size_t chunks = ((size_t)p->B + nb - 1) / nb;
+    nb = ((size_t)p->B + chunks - 1) / chunks;
+    pl->nb = (int)nb;
+    pl->y_bytes = ganet_align_up(nb * per_img, 256);
+    pl->gy_bytes = pl->y_bytes;
+    pl->gxc_bytes = ganet_align_up(nb * (size_t)p->H * p->W * pl->Cp * 4, 256);
+    pl->wqt_bytes = ganet_align_up(N * pl->Cp * 4, 256);
+    pl->wsp_bytes = pl->wqt_bytes;   // two bf16 planes
+    // grad_x is built per chunk in gxc and added to the caller's tensor: no full-size copy
+    pl->gxh_bytes = 0;
+  }
   return GANET_OK;
 }
 
@@ -430,7 +702,7 @@ using namespace ganet_dcn;
 extern "C" size_t ganet_deform_conv_backward_workspace_bytes(const ganet_dcn_params *p) {
   BwdPlan pl;
   if (make_bwd_plan(p, &pl) != GANET_OK) return 0;
-  return pl.xh_bytes + pl.gxh_bytes + pl.go_bytes + pl.wp_bytes + pl.gwp_bytes;
+  return pl.total();
 }
 
 extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
@@ -448,7 +720,7 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
   BwdPlan pl;
   const int rc = make_bwd_plan(p, &pl);
   if (rc != GANET_OK) return rc;
-  const size_t need = pl.xh_bytes + pl.gxh_bytes + pl.go_bytes + pl.wp_bytes + pl.gwp_bytes;
+  const size_t need = pl.total();
   if (workspace_bytes < need) return GANET_ERR_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
@@ -514,6 +786,98 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
   a.cpg = pl.Cp / p->deformable_groups;   // dg > 1 implies Cp == Cin
   a.P = P;
 
+  if (pl.commuted && (need_in || grad_weight)) {
+    unsigned char *cw = ws + pl.xh_bytes + pl.gxh_bytes + pl.go_bytes + pl.wp_bytes + pl.gwp_bytes;
+    float *yb = reinterpret_cast<float *>(cw);
+    float *gyb = reinterpret_cast<float *>(cw + pl.y_bytes);
+    float *gxc = reinterpret_cast<float *>(cw + pl.y_bytes + pl.gy_bytes);
+    float *wqt = reinterpret_cast<float *>(cw + pl.y_bytes + pl.gy_bytes + pl.gxc_bytes);
+    unsigned short *wsp = reinterpret_cast<unsigned short *>(cw + pl.y_bytes + pl.gy_bytes +
+                                                             pl.gxc_bytes + pl.wqt_bytes);
+    const int N = T * p->Cout;
+    if (need_in) {
+      hipLaunchKernelGGL(bwd_pack_weight_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256),
+                         0, s, static_cast<const float *>(weight), wp, p->Cout, p->Cin, T, pl.Cp);
+      hipLaunchKernelGGL(bwd_transpose_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
+                         s, wp, wqt, N, pl.Cp);
+      hipLaunchKernelGGL(bwd_split_rows_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
+                         s, wp, wsp, (long long)N * pl.Cp);
+      if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+      const size_t off_elems = (size_t)p->B * 2 * T * HWo;
+      if (hipMemsetAsync(grad_offset, 0, off_elems * 4, s) != hipSuccess) return GANET_ERR_HIP;
+      if (grad_mask && hipMemsetAsync(grad_mask, 0, off_elems * 2, s) != hipSuccess)
+        return GANET_ERR_HIP;
+    }
+    if (grad_weight && hipMemsetAsync(gwp, 0, pl.gwp_bytes, s) != hipSuccess) return GANET_ERR_HIP;
+    for (int img0 = 0; img0 < p->B; img0 += pl.nb) {
+      const int nimg = p->B - img0 < pl.nb ? p->B - img0 : pl.nb;
+      const long long M = (long long)nimg * HW;
+      const float *xc = a.xh + (size_t)img0 * HW * pl.Cp;
+      if (need_in) {
+        // per-tap products: three bf16 passes over high/low splits (as the forward forms them)
+        const int rc2 = cts_gemm_f32_split(xc, wsp, yb, M, pl.Cp, N, s);
+        if (rc2 != GANET_OK) return rc2;
+      }
+      if (hipMemsetAsync(gyb, 0, (size_t)M * N * 4, s) != hipSuccess) return GANET_ERR_HIP;
+      BwdCtsArgs c;
+      c.y = need_in ? yb : nullptr;
+      c.gy = gyb;
+      c.go = a.go;
+      c.offset = offset;
+      c.mask = mask;
+      c.goff = grad_offset;
+      c.gmask = grad_mask;
+      c.img0 = img0;
+      c.nimg = nimg;
+      c.H = p->H;
+      c.W = p->W;
+      c.Ho = pl.Ho;
+      c.Wo = pl.Wo;
+      c.Cout = p->Cout;
+      c.T = T;
+      c.kW = p->kW;
+      c.pH = p->pH;
+      c.pW = p->pW;
+      c.dH = p->dH;
+      c.dW = p->dW;
+      const long long groups = ((long long)nimg * HWo + 1) / 2;
+      long long nblk = (groups + CS_WAVES - 1) / CS_WAVES;
+      if (nblk > 256 * 16) nblk = 256 * 16;
+      hipLaunchKernelGGL(cts_bwd_sample_kernel, dim3((unsigned)nblk, (unsigned)(p->Cout / 64)),
+                         dim3(CS_WAVES * 64), 0, s, c);
+      if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+      if (need_in) {
+        const int rc2 = cts_gemm_f32(gyb, wqt, gxc, M, N, pl.Cp, s);
+        if (rc2 != GANET_OK) return rc2;
+        float *gx = static_cast<float *>(grad_x);
+        if (p->x_layout == GANET_NHWC) {
+          hipLaunchKernelGGL(bwd_add_rows_kernel, dim3(blocks_for(M * p->Cin)), dim3(256), 0, s, gxc,
+                             gx + (size_t)img0 * HW * p->Cin, M, p->Cin, pl.Cp);
+        } else {
+          dim3 grid((HW + 63) / 64, (pl.Cp + 63) / 64, nimg);
+          hipLaunchKernelGGL(bwd_add_nhwc_to_nchw_kernel, grid, dim3(256), 0, s, gxc,
+                             gx + (size_t)img0 * p->Cin * HW, p->Cin, HW, pl.Cp);
+        }
+        if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+      }
+      if (grad_weight) {
+        const int nblocks = (N / 64) * (pl.Cp / 64);
+        long long split = 1024 / nblocks + 1;
+        const long long maxsplit = (M / 2 + 255) / 256;   // >= 64 pixel pairs per wavefront
+        if (split > maxsplit) split = maxsplit;
+        if (split < 1) split = 1;
+        hipLaunchKernelGGL(cts_bwd_wgrad_kernel, dim3((unsigned)nblocks, (unsigned)split), dim3(256),
+                           0, s, gyb, xc, gwp, M, N, pl.Cp);
+        if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+      }
+    }
+    if (grad_weight) {
+      hipLaunchKernelGGL(bwd_unpack_add_weight_kernel,
+                         dim3(blocks_for((long long)p->Cout * p->Cin * T)), dim3(256), 0, s, gwp,
+                         static_cast<float *>(grad_weight), p->Cout, p->Cin, T, pl.Cp);
+      if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    }
+  } else {
   if (need_in) {
     hipLaunchKernelGGL(bwd_pack_weight_kernel, dim3(blocks_for((long long)T * p->Cout * pl.Cp)),
                        dim3(256), 0, s, static_cast<const float *>(weight), wp, p->Cout, p->Cin,
@@ -556,6 +920,7 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
                        static_cast<float *>(grad_weight), p->Cout, p->Cin, T, pl.Cp);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
+  }  // direct form
   if (grad_bias) {
     long long nb = (P + 1023) / 1024;
     if (nb > 1024) nb = 1024;

@@ -987,6 +987,25 @@ void launch_sample(const SampleArgs &a, hipStream_t s) {
 
 }  // namespace
 
+// y[M][N] = x[M][K] * wq[N][K]^T in exact float32 (the backward's GEMMs: per-tap products,
+// grad_x = grad_Y * Wq).  N % 64 == 0, K % 32 == 0.
+int cts_gemm_f32(const float *x, const float *wq, float *y, long long M, int K, int N,
+                 hipStream_t s) {
+  if (M <= 0 || N % 64 || K % 32) return GANET_ERR_UNSUPPORTED;
+  const int kh = K % 128 == 0 ? 128 : (K % 64 == 0 ? 64 : 32);
+  launch_gemm<float, float>(kh, x, wq, y, M, K, N, 0, s);
+  return ganet_check_launch();
+}
+
+// the same product as three bf16 passes (cts_gemm_split_kernel); wq_split = a high and a low
+// bf16 plane [N][K] each.  N % 32 == 0, K % 64 == 0.
+int cts_gemm_f32_split(const float *x, const void *wq_split, float *y, long long M, int K,
+                       int N, hipStream_t s) {
+  if (M <= 0 || N % 32 || K % 64) return GANET_ERR_UNSUPPORTED;
+  launch_gemm_split(x, wq_split, y, M, K, N, 0, s);
+  return ganet_check_launch();
+}
+
 // Applicable when the commuted order is cheaper and its assumptions hold: one
 // deformable group (one Y per tap) and fewer output than input channels.
 bool cts_split(const ganet_dcn_params *p, int Cp) {

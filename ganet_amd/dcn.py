@@ -169,11 +169,13 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
 
 def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
                          padding=(0, 0), dilation=(1, 1), groups=1, deformable_groups=1,
-                         mask=None, need_input=True, need_weight=True, need_bias=False):
+                         mask=None, need_input=True, need_weight=True, need_bias=False,
+                         algo=0):
     """Raw backward on the HIP library (float32).  Returns
     (grad_input, grad_offset, grad_mask, grad_weight, grad_bias); entries that were not
     asked for (or have no meaning without a mask) are None.  grad_input has the memory
-    format of `input`."""
+    format of `input`.  algo: 0 automatic, 1 direct (columns formed and consumed on chip),
+    2 commuted (Cout-wide rows through the per-tap products; where it applies)."""
     if not grad_output.is_cuda or not input.is_cuda:
         raise NotImplementedError
     if input.dtype != torch.float32:
@@ -204,6 +206,7 @@ def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
     p.dtype = _lib.GANET_F32
     p.x_layout = _lib.GANET_NHWC if nhwc else _lib.GANET_NCHW
     p.out_layout = _lib.GANET_NHWC if go_nhwc else _lib.GANET_NCHW
+    p.algo = algo
     grad_input = grad_offset = grad_mask = grad_weight = grad_bias = None
     if need_input:
         grad_input = torch.zeros_like(input)       # keeps the memory format

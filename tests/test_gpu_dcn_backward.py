@@ -68,6 +68,56 @@ def test_backward_matches_oracle(case, modulated, channels_last):
         channels_last and tx.is_contiguous(memory_format=torch.channels_last))
 
 
+COMMUTED = [
+    # shapes the commuted form takes (one deformable group, stride 1, Cout and Cin in 64-blocks)
+    (3, 256, 8, 25, 64, 1, 7, (1, 1), (0, 3), (1, 1), 1),     # the LFA's channel counts
+    (2, 256, 9, 11, 128, 3, 3, (1, 1), (1, 1), (1, 1), 1),    # two output blocks, 3x3
+    (2, 128, 10, 12, 64, 3, 3, (1, 1), (2, 2), (2, 2), 1),    # dilation 2
+    (1, 64, 7, 9, 64, 1, 9, (1, 1), (0, 4), (1, 1), 1),       # Cout == Cin: only when forced
+    (2, 192, 12, 10, 64, 1, 5, (1, 1), (0, 0), (1, 1), 1),    # output smaller than input
+]
+
+
+@pytest.mark.parametrize("case", COMMUTED)
+@pytest.mark.parametrize("modulated", [False, True])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_backward_direct_and_commuted_forms(case, modulated, algo):
+    """algo 1 = columns formed and consumed on chip, algo 2 = Cout-wide rows through the
+    per-tap products: both against the oracle, both memory formats."""
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 23, modulated)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg, mask=mask)
+    dev = torch.device("cuda", 0)
+    for channels_last in (False, True):
+        tx, toff, tw, tgo = (torch.from_numpy(a).to(dev) for a in (x, off, w, go))
+        tm = torch.from_numpy(mask).to(dev) if modulated else None
+        if channels_last:
+            tx = tx.contiguous(memory_format=torch.channels_last)
+            tgo = tgo.contiguous(memory_format=torch.channels_last)
+        gi, goff, gm, gw, gb = dcn.deform_conv_backward(
+            tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm, need_bias=modulated, algo=algo)
+        close(gi, ref["grad_x"], "grad_x")
+        close(goff, ref["grad_offset"], "grad_offset")
+        close(gw, ref["grad_weight"], "grad_weight")
+        if modulated:
+            close(gm, ref["grad_mask"], "grad_mask")
+            close(gb, ref["grad_bias"], "grad_bias")
+    # weight gradient alone (no per-tap products, no coordinate gradients)
+    _, _, _, gw, _ = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm,
+                                              need_input=False, algo=algo)
+    close(gw, ref["grad_weight"], "grad_weight (alone)")
+
+
+def test_commuted_form_is_refused_where_it_does_not_apply():
+    dev = torch.device("cuda", 0)
+    x = torch.zeros(1, 64, 6, 6, device=dev)
+    with pytest.raises(_lib.GanetError):     # stride 2
+        dcn.deform_conv_backward(x, torch.zeros(1, 18, 3, 3, device=dev),
+                                 torch.zeros(64, 64, 3, 3, device=dev),
+                                 torch.zeros(1, 64, 3, 3, device=dev), (2, 2), (1, 1), (1, 1),
+                                 algo=2)
+
+
 def test_autograd_through_the_modules():
     case = CASES[0]
     B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case

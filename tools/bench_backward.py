@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--algo", type=int, default=0, help="0 automatic, 1 direct, 2 commuted")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     B, Cin, H, W, K, Cout = args.batch, 256, 40, 100, 7, 64
@@ -42,12 +43,18 @@ def main():
 
     t_f = timed(lambda: dcn.deform_conv_forward(tx, toff, tw, (1, 1), (0, 3), (1, 1)))
     t_i = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, 3), (1, 1),
-                                                 need_input=True, need_weight=False))
+                                                 need_input=True, need_weight=False,
+                                                 algo=args.algo))
     t_w = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, 3), (1, 1),
-                                                 need_input=False, need_weight=True))
-    print(json.dumps(dict(batch=B, channels_last=args.channels_last, forward_ms=t_f,
-                          backward_input_ms=t_i, backward_weight_ms=t_w,
-                          train_images_per_s=B / ((t_f + t_i + t_w) * 1e-3))))
+                                                 need_input=False, need_weight=True,
+                                                 algo=args.algo))
+    t_b = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, 3), (1, 1),
+                                                 need_input=True, need_weight=True,
+                                                 algo=args.algo))
+    print(json.dumps(dict(batch=B, channels_last=args.channels_last, algo=args.algo,
+                          forward_ms=t_f, backward_input_ms=t_i, backward_weight_ms=t_w,
+                          backward_both_ms=t_b,
+                          train_images_per_s=B / ((t_f + t_b) * 1e-3))))
 
 
 if __name__ == "__main__":
