@@ -158,9 +158,14 @@ int ganet_deform_conv_forward(const void *x, const float *offset,
  * grad_x and grad_offset are computed together (both NULL to skip them, as when only
  * the weight needs a gradient); grad_mask is required with them when mask != NULL;
  * grad_weight and grad_bias may each be NULL.  There is no `columns` buffer and no
- * im2col_step.  Unsupported (GANET_ERR_UNSUPPORTED): other dtypes, conv groups > 1,
- * deformable groups whose channel count is not a multiple of 32, fuse_relu /
- * offset_is_points / weight_is_packed. */
+ * im2col_step.  p->algo picks the form: 1 = direct (the columns are formed and consumed
+ * on chip), 2 = commuted (Cout-wide rows scattered / gathered through the per-tap
+ * products Y_t = X * W_t^T, grad_x and grad_weight as GEMMs; one deformable group,
+ * stride 1, Cout and the padded Cin multiples of 64, else GANET_ERR_UNSUPPORTED),
+ * 0 = commuted where it applies and 2 * Cout <= Cin.  Unsupported
+ * (GANET_ERR_UNSUPPORTED): other dtypes, conv groups > 1, deformable groups whose
+ * channel count is not a multiple of 32, fuse_relu / offset_is_points /
+ * weight_is_packed. */
 size_t ganet_deform_conv_backward_workspace_bytes(const ganet_dcn_params *p);
 int ganet_deform_conv_backward(const void *x, const float *offset, const float *mask,
                                const void *weight, const void *grad_out, void *grad_x,
