@@ -1018,6 +1018,11 @@ bool cts_applicable(const ganet_dcn_params *p, int Cp, int CoutP) {
   // the GEMM may run as three bf16 passes (cts_split) or the caller asks for it.
   if (p->dtype == GANET_F32 && p->mfma_bf16 != 1 && !cts_split(p, Cp) && p->algo != 2)
     return false;
+  // one image's Y must stay below 2 GiB (32-bit byte offsets in the sampling kernel's
+  // buffer window); larger maps take the fused kernel
+  const size_t es = (p->dtype == GANET_F32 && p->mfma_bf16 != 1) ? 4 : 2;
+  const size_t img_y = (size_t)p->H * p->W * p->kH * p->kW * CoutP * es;
+  if (img_y >= 0x7fffffffull) return false;
   return p->deformable_groups == 1 && p->groups == 1 && 2 * CoutP <= Cp &&
          p->sH == 1 && p->sW == 1 && p->kH * p->kW <= 64;
 }

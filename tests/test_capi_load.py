@@ -85,6 +85,29 @@ def test_dcn_workspace_and_validation_without_gpu():
     assert rc == _lib.GANET_ERR_WORKSPACE
 
 
+def test_algorithm_choice_is_host_logic():
+    """ganet_deform_conv_algorithm answers without a GPU: the LFA's 256 -> 64 in bf16 takes the
+    contract-then-sample pair; a map whose per-image Y would pass 2 GiB falls back to the fused
+    kernel instead of failing; the commuted backward asks for more workspace than the direct."""
+    L = _lib.lib()
+    lfa = _dcn_params(B=4, Cin=256, H=40, W=100, Cout=64, dtype=_lib.GANET_BF16, x_layout=1,
+                      out_layout=1)
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(lfa)) == 2
+    huge = _dcn_params(B=1, Cin=256, H=1400, W=1400, Cout=64, kW=9, pW=4, dtype=_lib.GANET_BF16,
+                       x_layout=1, out_layout=1)      # Y of one image: 2.26 GB
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(huge)) == 1
+    forced = _dcn_params(B=1, Cin=256, H=1400, W=1400, Cout=64, kW=9, pW=4, dtype=_lib.GANET_BF16,
+                         x_layout=1, out_layout=1, algo=2)
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(forced)) == 0
+    direct = _dcn_params(B=4, Cin=256, H=40, W=100, Cout=64, x_layout=1, out_layout=1, algo=1)
+    commuted = _dcn_params(B=4, Cin=256, H=40, W=100, Cout=64, x_layout=1, out_layout=1, algo=2)
+    wd = L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(direct))
+    wc = L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(commuted))
+    assert 0 < wd < wc
+    strided = _dcn_params(B=4, Cin=256, H=40, W=100, Cout=64, sW=2, algo=2)
+    assert L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(strided)) == 0
+
+
 def test_decode_validation_without_gpu():
     L = _lib.lib()
     p = _lib.DecodeParams()
