@@ -135,4 +135,8 @@ int cts_gemm_f32(const float *x, const float *wq, float *y, long long M, int K, 
 int cts_gemm_f32_split(const float *x, const void *wq_split, float *y, long long M, int K,
                        int N, hipStream_t s);
 
+// y[M][ldy] (+)= x * wq^T with a long K and N <= 256 output columns (x read once)
+int cts_gemm_f32_split_wide(const float *x, const void *wq_split, float *y, long long M, int K,
+                            int N, int ldy, int accumulate, hipStream_t s);
+
 }  // namespace ganet_dcn

@@ -686,7 +686,7 @@ int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
     pl->gy_bytes = pl->y_bytes;
     pl->gxc_bytes = ganet_align_up(nb * (size_t)p->H * p->W * pl->Cp * 4, 256);
     pl->wqt_bytes = ganet_align_up(N * pl->Cp * 4, 256);
-    pl->wsp_bytes = pl->wqt_bytes;   // two bf16 planes
+    pl->wsp_bytes = 2 * pl->wqt_bytes;   // Wq and its transpose, two bf16 planes each
     // grad_x is built per chunk in gxc and added to the caller's tensor: no full-size copy
     pl->gxh_bytes = 0;
   }
@@ -802,6 +802,8 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
                          s, wp, wqt, N, pl.Cp);
       hipLaunchKernelGGL(bwd_split_rows_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
                          s, wp, wsp, (long long)N * pl.Cp);
+      hipLaunchKernelGGL(bwd_split_rows_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
+                         s, wqt, wsp + 2 * (size_t)N * pl.Cp, (long long)N * pl.Cp);
       if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
       const size_t off_elems = (size_t)p->B * 2 * T * HWo;
       if (hipMemsetAsync(grad_offset, 0, off_elems * 4, s) != hipSuccess) return GANET_ERR_HIP;
@@ -846,8 +848,18 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
       hipLaunchKernelGGL(cts_bwd_sample_kernel, dim3((unsigned)nblk, (unsigned)(p->Cout / 64)),
                          dim3(CS_WAVES * 64), 0, s, c);
       if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
-      if (need_in) {
-        const int rc2 = cts_gemm_f32(gyb, wqt, gxc, M, N, pl.Cp, s);
+      if (need_in && pl.Cp <= 256 && p->x_layout == GANET_NHWC && pl.Cp == p->Cin) {
+        // grad_x += grad_Y * Wq straight into the caller's channel-last tensor (three bf16
+        // passes, K-outer kernel: grad_Y is read once)
+        float *gx = static_cast<float *>(grad_x) + (size_t)img0 * HW * p->Cin;
+        const int rc2 = cts_gemm_f32_split_wide(gyb, wsp + 2 * (size_t)N * pl.Cp, gx, M, N, pl.Cp,
+                                                p->Cin, 1, s);
+        if (rc2 != GANET_OK) return rc2;
+      } else if (need_in) {
+        const int rc2 = pl.Cp <= 256
+                            ? cts_gemm_f32_split_wide(gyb, wsp + 2 * (size_t)N * pl.Cp, gxc, M, N,
+                                                      pl.Cp, pl.Cp, 0, s)
+                            : cts_gemm_f32(gyb, wqt, gxc, M, N, pl.Cp, s);
         if (rc2 != GANET_OK) return rc2;
         float *gx = static_cast<float *>(grad_x);
         if (p->x_layout == GANET_NHWC) {

@@ -631,6 +631,141 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_split_kernel(
 #undef GANET_STAMP
 }
 
+// ---- Y (+)= X * Wq^T for float32 tensors with a long K and few output columns ----------
+// (the backward's grad_x = grad_Y * Wq: K = T*Cout = 448, N = Cin = 256).  Three bf16
+// passes over high/low splits like cts_gemm_split_kernel, but with the loops the other way
+// round: a wavefront owns 32 rows and keeps the accumulators of ALL NS 32-column slices
+// live while it walks K in chunks of 64, so x is read once (the slice-outer kernel reads it
+// once per slice - 8 times here, which is why it measured no faster than the float32 MFMA).
+// The weight chunk of all slices (N x 64 x two planes) sits in LDS, one chunk at a time.
+template <int NS>
+__global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_split_wide_kernel(
+    const float *__restrict__ x, const bf16_t *__restrict__ wq, float *__restrict__ y,
+    long long M, int K, int ldy, int accumulate) {
+  constexpr int KC = 64, NQ = KC / 16, EPL = 8;
+  constexpr int N = NS * 32;
+  constexpr int LDB = KC + EPL;                 // +16 B: conflict-free ds_read_b128
+  constexpr int P_BYTES = N * LDB * 2;          // one plane of one chunk
+  constexpr int NT = GEMM_WAVES * 64;
+  constexpr int YROW = 32 * 4 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * P_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char s_y[GEMM_WAVES * 32 * YROW];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const long long m0 = ((long long)blockIdx.x * GEMM_WAVES + wid) * 32;
+  const long long r = m0 + i;
+  const float *xrow = x + (r < M ? r : M - 1) * K + h * EPL;
+  const bf16_t *wq_lo = wq + (size_t)N * K;
+  const int kchunks = K / KC;
+
+  constexpr int PPP = N * (KC / EPL);           // 16-byte pieces per plane and chunk
+  constexpr int BPT = 2 * PPP / NT;
+  static_assert((2 * PPP) % NT == 0, "weight chunk must split evenly over the threads");
+  auto stage_b = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int q = tid + j * NT;
+      const int pl = q / PPP, q2 = q - pl * PPP;
+      const int rr = q2 / (KC / EPL), pc = q2 - rr * (KC / EPL);
+      const u32x4 v = ldg128((pl ? wq_lo : wq) + ((size_t)rr * K + kc * KC + pc * EPL));
+      *reinterpret_cast<u32x4 *>(s_b + pl * P_BYTES + (rr * LDB + pc * EPL) * 2) = v;
+    }
+  };
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  u32x4 raw[2 * NQ];
+  auto load_a = [&](int kc) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      raw[2 * q] = ldg128(xrow + kc * KC + q * 16);
+      raw[2 * q + 1] = ldg128(xrow + kc * KC + q * 16 + 4);
+    }
+  };
+  bf16x8 fa_hi[NQ], fa_lo[NQ];
+  auto split_a = [&]() {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      unsigned int hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const u32x4 &v = e < 2 ? raw[2 * q] : raw[2 * q + 1];
+        const float a0 = __uint_as_float(v[(2 * e) & 3]);
+        const float a1 = __uint_as_float(v[(2 * e + 1) & 3]);
+        const bf16x2 ph = {(__bf16)a0, (__bf16)a1};
+        const unsigned int uh = __builtin_bit_cast(unsigned int, ph);
+        const float r0 = a0 - __uint_as_float(uh << 16);
+        const float r1 = a1 - __uint_as_float(uh & 0xffff0000u);
+        const bf16x2 pl = {(__bf16)r0, (__bf16)r1};
+        hi[e] = uh;
+        lo[e] = __builtin_bit_cast(unsigned int, pl);
+      }
+      const u32x4 ph4 = {hi[0], hi[1], hi[2], hi[3]};
+      const u32x4 pl4 = {lo[0], lo[1], lo[2], lo[3]};
+      fa_hi[q] = __builtin_bit_cast(bf16x8, ph4);
+      fa_lo[q] = __builtin_bit_cast(bf16x8, pl4);
+    }
+  };
+
+  f32x16 acc[NS];
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[sl][e] = 0.f;
+
+  load_a(0);
+  for (int kc = 0; kc < kchunks; ++kc) {
+    __syncthreads();            // the previous chunk's weights have been read
+    stage_b(kc);
+    split_a();
+    if (kc + 1 < kchunks) load_a(kc + 1);
+    __syncthreads();
+    const bf16_t *bh = reinterpret_cast<const bf16_t *>(s_b) + i * LDB + h * EPL;
+    const bf16_t *bl = reinterpret_cast<const bf16_t *>(s_b + P_BYTES) + i * LDB + h * EPL;
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const bf16x8 fh = *reinterpret_cast<const bf16x8 *>(bh + sl * 32 * LDB + q * 16);
+        const bf16x8 fl = *reinterpret_cast<const bf16x8 *>(bl + sl * 32 * LDB + q * 16);
+        // rows = outputs, columns = pixels; small terms first
+        acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, fa_hi[q], acc[sl], 0, 0, 0);
+        acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fa_lo[q], acc[sl], 0, 0, 0);
+        acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fa_hi[q], acc[sl], 0, 0, 0);
+      }
+  }
+
+  // lane (i, h), registers 4g..4g+3 of slice sl hold outputs sl*32 + 8g + 4h + 0..3 of pixel i
+  unsigned char *ys = s_y + wid * 32 * YROW;
+  const int pc = lane & 7, rq = lane >> 3;       // 8 lanes x 16 B per 32-float row
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl) {
+    float *yr = reinterpret_cast<float *>(ys + i * YROW) + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {acc[sl][4 * g], acc[sl][4 * g + 1], acc[sl][4 * g + 2], acc[sl][4 * g + 3]};
+      *reinterpret_cast<f32x4 *>(yr + 8 * g) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int rr = ps * 8 + rq;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(ys + rr * YROW + pc * 16);
+      const long long mr = m0 + rr;
+      if (mr < M) {
+        float *dst = y + mr * ldy + sl * 32 + pc * 4;
+        if (accumulate) v += *reinterpret_cast<const f32x4 *>(dst);
+        *reinterpret_cast<f32x4 *>(dst) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // ---- out = sum over taps of bilinear samples of Y -----------------------------------
 struct SampleArgs {
   const void *y;        // [nimg*H*W][T*CoutP], first image of the chunk at row 0
@@ -1003,6 +1138,23 @@ int cts_gemm_f32_split(const float *x, const void *wq_split, float *y, long long
                        int N, hipStream_t s) {
   if (M <= 0 || N % 32 || K % 64) return GANET_ERR_UNSUPPORTED;
   launch_gemm_split(x, wq_split, y, M, K, N, 0, s);
+  return ganet_check_launch();
+}
+
+// y[M][ldy] (+)= x[M][K] * wq^T, wq_split = two bf16 planes [N][K]; N in {64, 128, 192, 256},
+// K % 64 == 0, ldy % 4 == 0: the K-outer kernel (x read once)
+int cts_gemm_f32_split_wide(const float *x, const void *wq_split, float *y, long long M, int K,
+                            int N, int ldy, int accumulate, hipStream_t s) {
+  if (M <= 0 || K % 64 || N % 64 || N > 256 || ldy % 4) return GANET_ERR_UNSUPPORTED;
+  const unsigned gx = (unsigned)((M + GEMM_WAVES * 32 - 1) / (GEMM_WAVES * 32));
+  const bf16_t *ww = static_cast<const bf16_t *>(wq_split);
+  const dim3 block(GEMM_WAVES * 64);
+  switch (N / 32) {
+    case 2: hipLaunchKernelGGL((cts_gemm_split_wide_kernel<2>), dim3(gx), block, 0, s, x, ww, y, M, K, ldy, accumulate); break;
+    case 4: hipLaunchKernelGGL((cts_gemm_split_wide_kernel<4>), dim3(gx), block, 0, s, x, ww, y, M, K, ldy, accumulate); break;
+    case 6: hipLaunchKernelGGL((cts_gemm_split_wide_kernel<6>), dim3(gx), block, 0, s, x, ww, y, M, K, ldy, accumulate); break;
+    default: hipLaunchKernelGGL((cts_gemm_split_wide_kernel<8>), dim3(gx), block, 0, s, x, ww, y, M, K, ldy, accumulate); break;
+  }
   return ganet_check_launch();
 }
 
