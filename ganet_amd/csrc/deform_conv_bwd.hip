@@ -586,6 +586,160 @@ __global__ __launch_bounds__(256) void cts_bwd_wgrad_kernel(const float *__restr
   }
 }
 
+// The same product on the bf16 matrix cores in three passes over high/low splits (the
+// float32 MFMA runs at the vector rate, and 64 x 64 blocks re-read gy and x 4 + 7 times).
+// One workgroup of 8 wavefronts owns 2*NTW*32 rows (n) x 128 columns (c) of gw and a share
+// of the pixels; wavefront w keeps NTW 32 x 32 accumulators (c tile w & 3, n half w >> 2).
+// K = pixels, 16 per step: 288 threads each fetch 8 pixels x 4 columns of gy or x as float32
+// (whole 16-byte loads, a pixel row contiguous across lanes), split them, and park them in
+// LDS pixel-major per column ([plane][k half][column][8 pixels] bf16: the 16 bytes a lane
+// reads are one MFMA operand, 32 lanes read 512 contiguous bytes); two buffers, one barrier
+// per step.  One atomic flush of 128-byte runs at the end.
+constexpr int WG_WAVES = 8;
+constexpr int WG_BC = 128;
+constexpr int WG_KS = 16;
+
+template <int NTW>
+__global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
+    const float *__restrict__ gy, const float *__restrict__ x, float *__restrict__ gw,
+    long long M, int N, int Cp) {
+  constexpr int BN = 2 * NTW * 32;
+  constexpr int NCOLS = BN + WG_BC;
+  constexpr int NQ = NCOLS / 4;                 // column quads
+  constexpr int HALF = NCOLS * 16;              // bytes of one k half of one plane
+  constexpr int BUF = 4 * HALF;                 // hi (two halves), lo (two halves)
+  static_assert(2 * NQ <= WG_WAVES * 64, "one fetch task per thread");
+  __shared__ __attribute__((aligned(16))) unsigned char s_t[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int ncb = Cp / WG_BC;
+  const int bn = blockIdx.x / ncb, bc = blockIdx.x - bn * ncb;
+  const int nb0 = bn * BN, cb0 = bc * WG_BC;
+  const int ct = wid & 3, nh = wid >> 2;
+
+  const long long nks = (M + WG_KS - 1) / WG_KS;
+  const long long per = (nks + gridDim.y - 1) / gridDim.y;
+  const long long ks_beg = (long long)blockIdx.y * per;
+  const long long ks_end = ks_beg + per < nks ? ks_beg + per : nks;
+  if (ks_beg >= ks_end) return;                 // the whole workgroup leaves together
+
+  // fetch task: pixel octet po of the step, column quad cq (gy columns first, then x)
+  const bool fetcher = tid < 2 * NQ;
+  const int po = tid >= NQ ? 1 : 0, cq = tid - po * NQ;
+  const bool from_gy = 4 * cq < BN;
+  const float *src = from_gy ? gy + nb0 + 4 * cq : x + cb0 + (4 * cq - BN);
+  const long long ld = from_gy ? N : Cp;
+  u32x4 raw[8];
+  auto fetch = [&](long long ks) {
+    const long long q0 = ks * WG_KS + po * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long q = q0 + j;
+      const u32x4 v = ldg128(src + (q < M ? q : M - 1) * ld);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      raw[j] = q < M ? v : z;
+    }
+  };
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  auto park = [&](int buf) {
+    unsigned char *dst = s_t + buf * BUF + po * HALF + (4 * cq) * 16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned int hi[4], lo[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float a0 = __uint_as_float(raw[2 * jj][e]);
+        const float a1 = __uint_as_float(raw[2 * jj + 1][e]);
+        const bf16x2 ph = {(__bf16)a0, (__bf16)a1};
+        const unsigned int uh = __builtin_bit_cast(unsigned int, ph);
+        const float r0 = a0 - __uint_as_float(uh << 16);
+        const float r1 = a1 - __uint_as_float(uh & 0xffff0000u);
+        const bf16x2 pl = {(__bf16)r0, (__bf16)r1};
+        hi[jj] = uh;
+        lo[jj] = __builtin_bit_cast(unsigned int, pl);
+      }
+      const u32x4 h4 = {hi[0], hi[1], hi[2], hi[3]};
+      const u32x4 l4 = {lo[0], lo[1], lo[2], lo[3]};
+      *reinterpret_cast<u32x4 *>(dst + e * 16) = h4;
+      *reinterpret_cast<u32x4 *>(dst + 2 * HALF + e * 16) = l4;
+    }
+  };
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (fetcher) {
+    fetch(ks_beg);
+    park(0);
+  }
+  __syncthreads();
+  for (long long ks = ks_beg; ks < ks_end; ++ks) {
+    const int buf = (int)(ks - ks_beg) & 1;
+    const bool more = ks + 1 < ks_end;
+    if (fetcher && more) fetch(ks + 1);
+    const unsigned char *b = s_t + buf * BUF + h * HALF;
+    const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(b + (BN + ct * 32 + i) * 16);
+    const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(b + 2 * HALF + (BN + ct * 32 + i) * 16);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = (nh * NTW + t) * 32 + i;
+      const bf16x8 gh = *reinterpret_cast<const bf16x8 *>(b + col * 16);
+      const bf16x8 gl = *reinterpret_cast<const bf16x8 *>(b + 2 * HALF + col * 16);
+      // rows = n (grad_Y columns), columns = c (x channels); small terms first
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, xh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh, acc[t], 0, 0, 0);
+    }
+    if (fetcher && more) park(buf ^ 1);
+    __syncthreads();
+  }
+
+  // lane (i, h), register r of tile t: row (r & 3) + 8 (r >> 2) + 4 h, column i
+  float *out = gw + (size_t)(nb0 + nh * NTW * 32 + 4 * h) * Cp + cb0 + ct * 32 + i;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      unsafeAtomicAdd(out + (size_t)(t * 32 + (r & 3) + 8 * (r >> 2)) * Cp, acc[t][r]);
+}
+
+// Launches the split kernel where its tiling fits (N a multiple of 64 * NTW for an
+// instantiated NTW, Cp a multiple of 128); false = use cts_bwd_wgrad_kernel.
+bool launch_wgrad_split(const float *gy, const float *x, float *gw, long long M, int N, int Cp,
+                        hipStream_t s) {
+  if (getenv("GANET_BWD_WGRAD_F32")) return false;   // A/B knob
+  if (N % 64 || Cp % WG_BC || M < 1) return false;
+  const int m = N / 64;
+  int ntw = 0;
+  for (int cand : {7, 9, 5, 4, 3, 2, 1})
+    if (m % cand == 0) {
+      ntw = cand;
+      break;
+    }
+  if (!ntw) return false;
+  const int gx = (m / ntw) * (Cp / WG_BC);
+  const long long nks = (M + WG_KS - 1) / WG_KS;
+  long long split = 256 / gx;                       // one workgroup per CU
+  if (split > nks / 8) split = nks / 8;             // >= 8 steps between flushes
+  if (split < 1) split = 1;
+  const dim3 grid((unsigned)gx, (unsigned)split), block(WG_WAVES * 64);
+  switch (ntw) {
+    case 1: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<1>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
+    case 2: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<2>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
+    case 3: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<3>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
+    case 4: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<4>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
+    case 5: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<5>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
+    case 7: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<7>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
+    default: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<9>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
+  }
+  return true;
+}
+
 // float32 matrix -> a high and a low bf16 plane (v = hi + lo up to 2^-18 |v|), the operand
 // form of cts_gemm_split_kernel
 __global__ __launch_bounds__(256) void bwd_split_rows_kernel(const float *__restrict__ src,
@@ -872,7 +1026,9 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
         }
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
       }
-      if (grad_weight) {
+      if (grad_weight && launch_wgrad_split(gyb, xc, gwp, M, N, pl.Cp, s)) {
+        if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+      } else if (grad_weight) {
         const int nblocks = (N / 64) * (pl.Cp / 64);
         long long split = 1024 / nblocks + 1;
         const long long maxsplit = (M / 2 + 255) / 256;   // >= 64 pixel pairs per wavefront

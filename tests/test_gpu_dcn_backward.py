@@ -75,6 +75,12 @@ COMMUTED = [
     (2, 128, 10, 12, 64, 3, 3, (1, 1), (2, 2), (2, 2), 1),    # dilation 2
     (1, 64, 7, 9, 64, 1, 9, (1, 1), (0, 4), (1, 1), 1),       # Cout == Cin: only when forced
     (2, 192, 12, 10, 64, 1, 5, (1, 1), (0, 0), (1, 1), 1),    # output smaller than input
+    # the other tile counts of the split weight-gradient kernel (T*Cout/64 = 5, 4, 6, 2, 1)
+    (1, 128, 6, 7, 64, 1, 5, (1, 1), (0, 2), (1, 1), 1),
+    (1, 128, 6, 7, 64, 2, 2, (1, 1), (0, 0), (1, 1), 1),
+    (1, 128, 5, 9, 128, 1, 3, (1, 1), (0, 1), (1, 1), 1),
+    (1, 128, 5, 9, 128, 1, 1, (1, 1), (0, 0), (1, 1), 1),
+    (1, 128, 5, 9, 64, 1, 1, (1, 1), (0, 0), (1, 1), 1),
 ]
 
 
