@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void bwd_unpack_add_weight_kernel(
 // deformable_col2im / col2im_coord (deform_conv_cuda_kernel.cu:279-427).
 struct BwdCtsArgs {
   const float *y;        // [nimg*H*W][N] per-tap products of this chunk (nullptr: no coordinate gradients)
-  float *gy;             // same shape, zeroed, accumulated into
+  float *gy;             // same shape, zeroed, accumulated into (nullptr: cts_bwd_bin_kernel forms it)
   const float *go;       // [B*Ho*Wo][Cout] channel-last grad_out (whole batch)
   const float *offset;   // whole batch
   const float *mask;     // whole batch or nullptr
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cts_bwd_sample_kernel(BwdCtsArg
             if (a.gmask) unsafeAtomicAdd(a.gmask + ((size_t)b * a.T + t) * HWo + hw, sm);
           }
         }
-        if (valid) {
+        if (valid && a.gy) {
           const float w1 = hh * hw_ * m, w2 = hh * lw * m, w3 = lh * hw_ * m, w4 = lh * lw * m;
           if (cx.x >= 0) {
             unsafeAtomicAdd(a.gy + cx.x + c0, w1 * g0);
@@ -522,6 +522,143 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cts_bwd_sample_kernel(BwdCtsArg
       }
       wave_sync_lds();
     }
+  }
+}
+
+// grad_Y without global atomics.  The L2 retires about one float add per channel and clock
+// (tools/atomicbw.hip: 300 G adds/s whatever the locality), which is what the scatter above
+// runs at; LDS adds are two orders of magnitude cheaper.  One workgroup owns BIN_Q consecutive
+// input pixels q of one image, one tap and one 64-channel block as a float tile in LDS.  It
+// walks ALL output pixels of the image: every thread forms one pixel's sampling position and
+// appends the corners that land in the tile to an LDS list (pixel, tile row, weight * mask);
+// half wavefronts then take the entries in turn, read the pixel's grad_out run (lane l owns
+// channels l and l + 32) and add into the tile.  The tile leaves once, as plain 16-byte
+// stores that cover every (q, tap) of the chunk: grad_Y needs no memset.  Each part scans the
+// whole image, so the form is used while an image has at most BIN_MAX_PARTS parts.  A list that
+// fills up (every sample of the image landing in one tile) makes the thread add its run itself
+// with LDS atomics.
+constexpr int BIN_Q = 128;
+constexpr int BIN_THREADS = 512;
+constexpr int BIN_CAP = 3968;             // list entries (tile + list = 78.5 KB: two workgroups per CU)
+constexpr int BIN_MAX_PARTS = 64;
+
+__global__ __launch_bounds__(BIN_THREADS) void cts_bwd_bin_kernel(BwdCtsArgs a, int parts) {
+  __shared__ __attribute__((aligned(16))) float s_tile[BIN_Q * 64];
+  __shared__ int s_ep[BIN_CAP];
+  __shared__ int s_eq[BIN_CAP];
+  __shared__ float s_ew[BIN_CAP];
+  __shared__ int s_cnt[BIN_THREADS / 32];
+  const int tid = threadIdx.x, l = tid & 31;
+  const int hwv = __builtin_amdgcn_readfirstlane(tid >> 6) * 2 + ((tid >> 5) & 1);   // half wavefront
+  const int HW = a.H * a.W, HWo = a.Ho * a.Wo;
+  const int N = a.T * a.Cout;
+  int task = blockIdx.x;
+  const int part = task % parts;
+  task /= parts;
+  const int t = task % a.T;
+  const int bl = task / a.T;
+  const int b = a.img0 + bl;
+  const int cb = blockIdx.y;
+  const int q0 = part * BIN_Q;
+  const int ti = t / a.kW, tj = t - ti * a.kW;
+
+  for (int k = tid; k < BIN_Q * 64 / 4; k += BIN_THREADS)
+    reinterpret_cast<f32x4 *>(s_tile)[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < BIN_THREADS / 32) s_cnt[tid] = 0;
+  __syncthreads();
+
+  const float *gob = a.go + (size_t)b * HWo * a.Cout + cb * 64;
+  const float *offb = a.offset + ((size_t)b * 2 * a.T + 2 * t) * HWo;
+  const float *mb = a.mask ? a.mask + ((size_t)b * a.T + t) * HWo : nullptr;
+  constexpr int NH = BIN_THREADS / 32, LCAP = BIN_CAP / NH, DU = 8;
+  // one pass over the image's output pixels, four pixels' offsets in flight per thread
+  for (int base = 0; base < HWo; base += 4 * BIN_THREADS) {
+    float oh[4], ow[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int hw = base + u * BIN_THREADS + tid;
+      const int hc = hw < HWo ? hw : HWo - 1;
+      oh[u] = ldg_f32(offb + hc);
+      ow[u] = ldg_f32(offb + HWo + hc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int hw = base + u * BIN_THREADS + tid;
+      if (hw >= HWo) continue;
+      const int ho = hw / a.Wo, wo = hw - ho * a.Wo;
+      const float h_im = (float)(ho - a.pH + ti * a.dH) + oh[u];
+      const float w_im = (float)(wo - a.pW + tj * a.dW) + ow[u];
+      if (!(h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W)) continue;
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+      const float hh = 1.f - lh, hw_ = 1.f - lw;
+      // the corner rows of this position: do any fall into [q0, q0 + BIN_Q)?
+      const int qa = h_low * a.W + w_low - q0;          // tile row of corner 1
+      if (qa + a.W + 1 < 0 || qa >= BIN_Q) continue;
+      const float m = mb ? ldg_f32(mb + hw) : 1.f;
+      const bool hl = h_low >= 0, hhi = h_low + 1 <= a.H - 1;
+      const bool wl = w_low >= 0, whi = w_low + 1 <= a.W - 1;
+      auto put = [&](bool ok, int r, float w) {
+        if (ok && r >= 0 && r < BIN_Q) {
+          const int own = r & (NH - 1);          // the half wavefront that owns tile row r
+          const int slot = atomicAdd(&s_cnt[own], 1);
+          if (slot < LCAP) {
+            s_ep[own * LCAP + slot] = hw;
+            s_eq[own * LCAP + slot] = r;
+            s_ew[own * LCAP + slot] = w * m;
+          } else {
+            // list full (far more samples than usual land in this tile): add the run here
+            const float *gp = gob + (size_t)hw * a.Cout;
+            for (int c = 0; c < 64; ++c) unsafeAtomicAdd(&s_tile[r * 64 + c], w * m * ldg_f32(gp + c));
+          }
+        }
+      };
+      put(hl && wl, qa, hh * hw_);
+      put(hl && whi, qa + 1, hh * lw);
+      put(hhi && wl, qa + a.W, lh * hw_);
+      put(hhi && whi, qa + a.W + 1, lh * lw);
+    }
+  }
+  __syncthreads();
+  // Half wavefront hwv owns the tile rows r with r % NH == hwv and walks its own list: plain
+  // read-modify-writes, in program order, on rows nobody else touches (the inline adds above
+  // ended at the barrier).  Eight entries' grad_out runs are in flight at a time.
+  const int cnt = s_cnt[hwv] < LCAP ? s_cnt[hwv] : LCAP;
+  const int lb = hwv * LCAP;
+  int e = 0;
+  for (; e + DU <= cnt; e += DU) {
+    float g0[DU], g1[DU], w[DU];
+    int r[DU];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const float *gp = gob + (size_t)s_ep[lb + e + u] * a.Cout + l;
+      g0[u] = ldg_f32(gp);
+      g1[u] = ldg_f32(gp + 32);
+      r[u] = s_eq[lb + e + u];
+      w[u] = s_ew[lb + e + u];
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      s_tile[r[u] * 64 + l] += w[u] * g0[u];
+      s_tile[r[u] * 64 + l + 32] += w[u] * g1[u];
+    }
+  }
+  for (; e < cnt; ++e) {
+    const float *gp = gob + (size_t)s_ep[lb + e] * a.Cout + l;
+    const float w = s_ew[lb + e];
+    const int r = s_eq[lb + e];
+    s_tile[r * 64 + l] += w * ldg_f32(gp);
+    s_tile[r * 64 + l + 32] += w * ldg_f32(gp + 32);
+  }
+  __syncthreads();
+
+  // rows of the tile that exist in the image leave as whole 256-byte runs
+  const int rows = HW - q0 < BIN_Q ? HW - q0 : BIN_Q;
+  float *dst = a.gy + ((size_t)bl * HW + q0) * N + t * a.Cout + cb * 64;
+  for (int k = tid; k < rows * 16; k += BIN_THREADS) {
+    const int r = k >> 4, c4 = k & 15;
+    *reinterpret_cast<f32x4 *>(dst + (size_t)r * N + c4 * 4) =
+        *reinterpret_cast<const f32x4 *>(s_tile + r * 64 + c4 * 4);
   }
 }
 
@@ -974,7 +1111,11 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
         const int rc2 = cts_gemm_f32_split(xc, wsp, yb, M, pl.Cp, N, s);
         if (rc2 != GANET_OK) return rc2;
       }
-      if (hipMemsetAsync(gyb, 0, (size_t)M * N * 4, s) != hipSuccess) return GANET_ERR_HIP;
+      // grad_Y: binned in LDS while an image has few tiles (every tile's workgroup scans the
+      // whole image), through global atomics otherwise
+      const int parts = (HW + BIN_Q - 1) / BIN_Q;
+      const bool binned = parts <= BIN_MAX_PARTS && !getenv("GANET_BWD_SCATTER_ATOMIC");
+      if (!binned && hipMemsetAsync(gyb, 0, (size_t)M * N * 4, s) != hipSuccess) return GANET_ERR_HIP;
       BwdCtsArgs c;
       c.y = need_in ? yb : nullptr;
       c.gy = gyb;
@@ -996,12 +1137,20 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
       c.pW = p->pW;
       c.dH = p->dH;
       c.dW = p->dW;
-      const long long groups = ((long long)nimg * HWo + 1) / 2;
-      long long nblk = (groups + CS_WAVES - 1) / CS_WAVES;
-      if (nblk > 256 * 16) nblk = 256 * 16;
-      hipLaunchKernelGGL(cts_bwd_sample_kernel, dim3((unsigned)nblk, (unsigned)(p->Cout / 64)),
-                         dim3(CS_WAVES * 64), 0, s, c);
-      if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+      if (binned) {
+        hipLaunchKernelGGL(cts_bwd_bin_kernel, dim3((unsigned)(nimg * T * parts), (unsigned)(p->Cout / 64)),
+                           dim3(BIN_THREADS), 0, s, c, parts);
+        if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+        c.gy = nullptr;
+      }
+      if (need_in || !binned) {
+        const long long groups = ((long long)nimg * HWo + 1) / 2;
+        long long nblk = (groups + CS_WAVES - 1) / CS_WAVES;
+        if (nblk > 256 * 16) nblk = 256 * 16;
+        hipLaunchKernelGGL(cts_bwd_sample_kernel, dim3((unsigned)nblk, (unsigned)(p->Cout / 64)),
+                           dim3(CS_WAVES * 64), 0, s, c);
+        if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+      }
       if (need_in && pl.Cp <= 256 && p->x_layout == GANET_NHWC && pl.Cp == p->Cin) {
         // grad_x += grad_Y * Wq straight into the caller's channel-last tensor (three bf16
         // passes, K-outer kernel: grad_Y is read once)

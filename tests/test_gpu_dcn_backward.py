@@ -114,6 +114,30 @@ def test_backward_direct_and_commuted_forms(case, modulated, algo):
     close(gw, ref["grad_weight"], "grad_weight (alone)")
 
 
+def test_commuted_form_when_every_sample_lands_on_one_spot():
+    """All pixels and taps sample the same position: the LDS list of the binned grad_Y
+    kernel (3968 entries per 128-pixel tile) overflows and the inline path takes over."""
+    B, Cin, H, W, Cout, kH, kW = 1, 128, 20, 60, 64, 1, 3
+    st, pad, dil = (1, 1), (0, 1), (1, 1)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, kH, kW)) * 0.2).astype(np.float32)
+    go = rng.standard_normal((B, Cout, H, W)).astype(np.float32)
+    off = np.zeros((B, 2 * kW, H, W), np.float32)
+    hh, ww = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    for t in range(kW):
+        off[0, 2 * t] = 3.3 - hh
+        off[0, 2 * t + 1] = 7.6 - (ww - pad[1] + t)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, 1)
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo = (torch.from_numpy(a).to(dev) for a in (x, off, w, go))
+    for algo in (1, 2):
+        gi, goff, _, gw, _ = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, 1, algo=algo)
+        close(gi, ref["grad_x"], "grad_x")
+        close(goff, ref["grad_offset"], "grad_offset")
+        close(gw, ref["grad_weight"], "grad_weight")
+
+
 def test_commuted_form_is_refused_where_it_does_not_apply():
     dev = torch.device("cuda", 0)
     x = torch.zeros(1, 64, 6, 6, device=dev)
