@@ -965,7 +965,14 @@ int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
   if (pl->commuted) {
     const size_t N = (size_t)pl->T * p->Cout;
     const size_t per_img = (size_t)p->H * p->W * N * 4;
-    size_t nb = (96ull << 20) / per_img;     // Y and grad_Y of a chunk stay in the Infinity Cache
+    // Y and grad_Y of a chunk: with the scatter binned in LDS, fewer and larger launches beat
+    // keeping both inside the Infinity Cache (B=32: 96 MB 1.05 ms, 128 MB 0.95, 256 MB 0.91)
+    size_t budget = 256ull << 20;
+    if (const char *e = getenv("GANET_BWD_BUDGET_MB")) {   // A/B knob: query and call must agree
+      const long long mb = atoll(e);
+      if (mb > 0) budget = (size_t)mb << 20;
+    }
+    size_t nb = budget / per_img;
     const size_t lim = (0x7fffffffull / 4) / ((size_t)p->H * p->W * N);   // 31-bit float indices
     if (nb > lim) nb = lim;
     if (nb < 1) nb = 1;

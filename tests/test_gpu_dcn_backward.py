@@ -138,6 +138,24 @@ def test_commuted_form_when_every_sample_lands_on_one_spot():
         close(gw, ref["grad_weight"], "grad_weight")
 
 
+def test_commuted_form_walks_the_batch_in_chunks(monkeypatch):
+    """A 1 MB budget for the per-tap products makes two chunks of the 3-image case (the
+    default budget holds 35 LFA-sized images, so small cases never leave the first chunk)."""
+    monkeypatch.setenv("GANET_BWD_BUDGET_MB", "1")
+    case = COMMUTED[0]
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 31, True)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg, mask=mask)
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo, tm = (torch.from_numpy(a).to(dev) for a in (x, off, w, go, mask))
+    gi, goff, gm, gw, _ = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm,
+                                                   algo=2)
+    close(gi, ref["grad_x"], "grad_x")
+    close(goff, ref["grad_offset"], "grad_offset")
+    close(gm, ref["grad_mask"], "grad_mask")
+    close(gw, ref["grad_weight"], "grad_weight")
+
+
 def test_commuted_form_is_refused_where_it_does_not_apply():
     dev = torch.device("cuda", 0)
     x = torch.zeros(1, 64, 6, 6, device=dev)
