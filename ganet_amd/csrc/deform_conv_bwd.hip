@@ -768,8 +768,11 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
   const bool from_gy = 4 * cq < BN;
   const float *src = from_gy ? gy + nb0 + 4 * cq : x + cb0 + (4 * cq - BN);
   const long long ld = from_gy ? N : Cp;
-  u32x4 raw[8];
-  auto fetch = [&](long long ks) {
+  // two register sets: raw holds the step that is parked next, ahead the one after it, so a
+  // step's rows have a whole step to arrive (one loop body, the sets rotate by moves: two
+  // unrolled bodies spilled)
+  u32x4 raw[8], ahead[8];
+  auto fetch = [&](u32x4 (&raw)[8], long long ks) {
     const long long q0 = ks * WG_KS + po * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -811,14 +814,15 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   if (fetcher) {
-    fetch(ks_beg);
+    fetch(raw, ks_beg);
     park(0);
+    if (ks_beg + 1 < ks_end) fetch(raw, ks_beg + 1);
+    if (ks_beg + 2 < ks_end) fetch(ahead, ks_beg + 2);
   }
   __syncthreads();
+#pragma unroll 1
   for (long long ks = ks_beg; ks < ks_end; ++ks) {
     const int buf = (int)(ks - ks_beg) & 1;
-    const bool more = ks + 1 < ks_end;
-    if (fetcher && more) fetch(ks + 1);
     const unsigned char *b = s_t + buf * BUF + h * HALF;
     const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(b + (BN + ct * 32 + i) * 16);
     const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(b + 2 * HALF + (BN + ct * 32 + i) * 16);
@@ -832,7 +836,12 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh, acc[t], 0, 0, 0);
     }
-    if (fetcher && more) park(buf ^ 1);
+    if (fetcher && ks + 1 < ks_end) park(buf ^ 1);
+    if (fetcher && ks + 2 < ks_end) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[j] = ahead[j];
+    }
+    if (fetcher && ks + 3 < ks_end) fetch(ahead, ks + 3);
     __syncthreads();
   }
 
