@@ -156,6 +156,27 @@ def test_commuted_form_walks_the_batch_in_chunks(monkeypatch):
     close(gw, ref["grad_weight"], "grad_weight")
 
 
+def test_commuted_form_with_the_atomic_scatter(monkeypatch):
+    """Maps above 512 tiles of 128 pixels form grad_Y through global atomics instead of the
+    LDS bins; the knob takes that path on a small case."""
+    monkeypatch.setenv("GANET_BWD_SCATTER_ATOMIC", "1")
+    case = COMMUTED[1]
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 37, True)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg, mask=mask)
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo, tm = (torch.from_numpy(a).to(dev) for a in (x, off, w, go, mask))
+    gi, goff, gm, gw, _ = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm,
+                                                   algo=2)
+    close(gi, ref["grad_x"], "grad_x")
+    close(goff, ref["grad_offset"], "grad_offset")
+    close(gm, ref["grad_mask"], "grad_mask")
+    close(gw, ref["grad_weight"], "grad_weight")
+    _, _, _, gw, _ = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm,
+                                              need_input=False, algo=2)
+    close(gw, ref["grad_weight"], "grad_weight (alone)")
+
+
 def test_commuted_form_is_refused_where_it_does_not_apply():
     dev = torch.device("cuda", 0)
     x = torch.zeros(1, 64, 6, 6, device=dev)

@@ -19,14 +19,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--algo", type=int, default=0, help="0 automatic, 1 direct, 2 commuted")
+    ap.add_argument("--hw", type=int, nargs=2, default=[40, 100], help="feature map H W")
+    ap.add_argument("--k", type=int, default=7, help="taps of the 1xK kernel")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    B, Cin, H, W, K, Cout = args.batch, 256, 40, 100, 7, 64
+    B, Cin, H, W, K, Cout = args.batch, 256, args.hw[0], args.hw[1], args.k, 64
     x, off, w, _ = synth.lfa_inputs(B, Cin, H, W, K, Cout=Cout, seed=0)
     tx, toff, tw = (torch.from_numpy(a).to(dev) for a in (x, off, w))
     if args.channels_last:
         tx = tx.contiguous(memory_format=torch.channels_last)
-    out = dcn.deform_conv_forward(tx, toff, tw, (1, 1), (0, 3), (1, 1))
+    out = dcn.deform_conv_forward(tx, toff, tw, (1, 1), (0, (K - 1) // 2), (1, 1))
     go = torch.randn_like(out)
 
     def timed(fn):
@@ -41,17 +43,17 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / args.steps
 
-    t_f = timed(lambda: dcn.deform_conv_forward(tx, toff, tw, (1, 1), (0, 3), (1, 1)))
-    t_i = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, 3), (1, 1),
+    t_f = timed(lambda: dcn.deform_conv_forward(tx, toff, tw, (1, 1), (0, (K - 1) // 2), (1, 1)))
+    t_i = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, (K - 1) // 2), (1, 1),
                                                  need_input=True, need_weight=False,
                                                  algo=args.algo))
-    t_w = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, 3), (1, 1),
+    t_w = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, (K - 1) // 2), (1, 1),
                                                  need_input=False, need_weight=True,
                                                  algo=args.algo))
-    t_b = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, 3), (1, 1),
+    t_b = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, (K - 1) // 2), (1, 1),
                                                  need_input=True, need_weight=True,
                                                  algo=args.algo))
-    print(json.dumps(dict(batch=B, channels_last=args.channels_last, algo=args.algo,
+    print(json.dumps(dict(batch=B, hw=[H, W], k=K, channels_last=args.channels_last, algo=args.algo,
                           forward_ms=t_f, backward_input_ms=t_i, backward_weight_ms=t_w,
                           backward_both_ms=t_b,
                           train_images_per_s=B / ((t_f + t_b) * 1e-3))))
