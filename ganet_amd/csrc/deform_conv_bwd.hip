@@ -398,6 +398,8 @@ struct BwdCtsArgs {
   const float *mask;     // whole batch or nullptr
   float *goff;           // zeroed, accumulated into
   float *gmask;          // zeroed, accumulated into, or nullptr
+  unsigned *geo_q;       // binned form: [nimg][T][Ho*Wo] packed (h_low + 1) << 16 | (w_low + 1), ~0u = outside
+  f32x2 *geo_f;          // same shape: (lh, lw)
   int img0, nimg;
   int H, W, Ho, Wo, Cout, T;
   int kW, pH, pW, dH, dW;
@@ -525,6 +527,36 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cts_bwd_sample_kernel(BwdCtsArg
   }
 }
 
+// Sampling geometry of one chunk, once per (image, tap, output pixel), for cts_bwd_bin_kernel:
+// floor of the position packed as (h_low + 1) << 16 | (w_low + 1) (~0u: the sample reads
+// nothing, deform_conv_cuda_kernel.cu:226) and its fractions (lh, lw).
+__global__ __launch_bounds__(256) void cts_bwd_geo_kernel(BwdCtsArgs a) {
+  const int HWo = a.Ho * a.Wo;
+  const long long total = (long long)a.nimg * a.T * HWo;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
+       k += (long long)gridDim.x * 256) {
+    const int hw = (int)(k % HWo);
+    const long long bt = k / HWo;
+    const int t = (int)(bt % a.T), bl = (int)(bt / a.T);
+    const int b = a.img0 + bl;
+    const int ti = t / a.kW, tj = t - ti * a.kW;
+    const int ho = hw / a.Wo, wo = hw - ho * a.Wo;
+    const float *op = a.offset + ((size_t)b * 2 * a.T + 2 * t) * HWo + hw;
+    const float h_im = (float)(ho - a.pH + ti * a.dH) + ldg_f32(op);
+    const float w_im = (float)(wo - a.pW + tj * a.dW) + ldg_f32(op + HWo);
+    unsigned pk = ~0u;
+    f32x2 fr = {0.f, 0.f};
+    if (h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W) {
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      pk = ((unsigned)(h_low + 1) << 16) | (unsigned)(w_low + 1);
+      fr[0] = h_im - (float)h_low;
+      fr[1] = w_im - (float)w_low;
+    }
+    a.geo_q[k] = pk;
+    a.geo_f[k] = fr;
+  }
+}
+
 // grad_Y without global atomics.  The L2 retires about one float add per channel and clock
 // (tools/atomicbw.hip: 300 G adds/s whatever the locality), which is what the scatter above
 // runs at; LDS adds are two orders of magnitude cheaper.  One workgroup owns BIN_Q consecutive
@@ -560,7 +592,6 @@ __global__ __launch_bounds__(BIN_THREADS) void cts_bwd_bin_kernel(BwdCtsArgs a, 
   const int b = a.img0 + bl;
   const int cb = blockIdx.y;
   const int q0 = part * BIN_Q;
-  const int ti = t / a.kW, tj = t - ti * a.kW;
 
   for (int k = tid; k < BIN_Q * 64 / 4; k += BIN_THREADS)
     reinterpret_cast<f32x4 *>(s_tile)[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -568,33 +599,29 @@ __global__ __launch_bounds__(BIN_THREADS) void cts_bwd_bin_kernel(BwdCtsArgs a, 
   __syncthreads();
 
   const float *gob = a.go + (size_t)b * HWo * a.Cout + cb * 64;
-  const float *offb = a.offset + ((size_t)b * 2 * a.T + 2 * t) * HWo;
+  const unsigned *gq = a.geo_q + ((size_t)bl * a.T + t) * HWo;
+  const f32x2 *gf = a.geo_f + ((size_t)bl * a.T + t) * HWo;
   const float *mb = a.mask ? a.mask + ((size_t)b * a.T + t) * HWo : nullptr;
   constexpr int NH = BIN_THREADS / 32, LCAP = BIN_CAP / NH, DU = 8;
-  // one pass over the image's output pixels, four pixels' offsets in flight per thread
+  // one pass over the image's output pixels: the packed corner of cts_bwd_geo_kernel decides
+  // in a few instructions whether a sample touches this tile (every tile scans every pixel)
   for (int base = 0; base < HWo; base += 4 * BIN_THREADS) {
-    float oh[4], ow[4];
+    unsigned pk[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int hw = base + u * BIN_THREADS + tid;
-      const int hc = hw < HWo ? hw : HWo - 1;
-      oh[u] = ldg_f32(offb + hc);
-      ow[u] = ldg_f32(offb + HWo + hc);
+      pk[u] = hw < HWo ? gq[hw] : ~0u;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int hw = base + u * BIN_THREADS + tid;
-      if (hw >= HWo) continue;
-      const int ho = hw / a.Wo, wo = hw - ho * a.Wo;
-      const float h_im = (float)(ho - a.pH + ti * a.dH) + oh[u];
-      const float w_im = (float)(wo - a.pW + tj * a.dW) + ow[u];
-      if (!(h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W)) continue;
-      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-      const float hh = 1.f - lh, hw_ = 1.f - lw;
-      // the corner rows of this position: do any fall into [q0, q0 + BIN_Q)?
+      if (pk[u] == ~0u) continue;
+      const int h_low = (int)(pk[u] >> 16) - 1, w_low = (int)(pk[u] & 0xffffu) - 1;
       const int qa = h_low * a.W + w_low - q0;          // tile row of corner 1
       if (qa + a.W + 1 < 0 || qa >= BIN_Q) continue;
+      const f32x2 fr = gf[hw];
+      const float lh = fr[0], lw = fr[1];
+      const float hh = 1.f - lh, hw_ = 1.f - lw;
       const float m = mb ? ldg_f32(mb + hw) : 1.f;
       const bool hl = h_low >= 0, hhi = h_low + 1 <= a.H - 1;
       const bool wl = w_low >= 0, whi = w_low + 1 <= a.W - 1;
@@ -921,10 +948,10 @@ struct BwdPlan {
   // commuted form
   bool commuted;
   int nb;                 // images per chunk
-  size_t y_bytes, gy_bytes, gxc_bytes, wqt_bytes, wsp_bytes;
+  size_t y_bytes, gy_bytes, gxc_bytes, wqt_bytes, wsp_bytes, geo_bytes;
   size_t total() const {
     return xh_bytes + gxh_bytes + go_bytes + wp_bytes + gwp_bytes + y_bytes + gy_bytes +
-           gxc_bytes + wqt_bytes + wsp_bytes;
+           gxc_bytes + wqt_bytes + wsp_bytes + geo_bytes;
   }
 };
 
@@ -970,7 +997,7 @@ int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
   if (p->algo == 2 && !can) return GANET_ERR_UNSUPPORTED;
   pl->commuted = can && (p->algo == 2 || (p->algo == 0 && 2 * p->Cout <= pl->Cp));
   pl->nb = 0;
-  pl->y_bytes = pl->gy_bytes = pl->gxc_bytes = pl->wqt_bytes = pl->wsp_bytes = 0;
+  pl->y_bytes = pl->gy_bytes = pl->gxc_bytes = pl->wqt_bytes = pl->wsp_bytes = pl->geo_bytes = 0;
   if (pl->commuted) {
     const size_t N = (size_t)pl->T * p->Cout;
     const size_t per_img = (size_t)p->H * p->W * N * 4;
@@ -994,6 +1021,9 @@ int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
     pl->gxc_bytes = ganet_align_up(nb * (size_t)p->H * p->W * pl->Cp * 4, 256);
     pl->wqt_bytes = ganet_align_up(N * pl->Cp * 4, 256);
     pl->wsp_bytes = 2 * pl->wqt_bytes;   // Wq and its transpose, two bf16 planes each
+    // sampling geometry of a chunk for the binned grad_Y: packed corner (4 B) + fractions (8 B)
+    pl->geo_bytes = ganet_align_up(nb * (size_t)pl->T * pl->Ho * pl->Wo * 4, 256) +
+                    ganet_align_up(nb * (size_t)pl->T * pl->Ho * pl->Wo * 8, 256);
     // grad_x is built per chunk in gxc and added to the caller's tensor: no full-size copy
     pl->gxh_bytes = 0;
   }
@@ -1101,6 +1131,7 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
     float *wqt = reinterpret_cast<float *>(cw + pl.y_bytes + pl.gy_bytes + pl.gxc_bytes);
     unsigned short *wsp = reinterpret_cast<unsigned short *>(cw + pl.y_bytes + pl.gy_bytes +
                                                              pl.gxc_bytes + pl.wqt_bytes);
+    unsigned char *geo = cw + pl.y_bytes + pl.gy_bytes + pl.gxc_bytes + pl.wqt_bytes + pl.wsp_bytes;
     const int N = T * p->Cout;
     if (need_in) {
       hipLaunchKernelGGL(bwd_pack_weight_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256),
@@ -1132,7 +1163,8 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
       const int parts = (HW + BIN_Q - 1) / BIN_Q;
       int max_parts = BIN_MAX_PARTS;
       if (const char *e = getenv("GANET_BWD_BIN_MAX_PARTS")) max_parts = atoi(e);   // A/B knob
-      const bool binned = parts <= max_parts && !getenv("GANET_BWD_SCATTER_ATOMIC");
+      const bool binned = parts <= max_parts && p->H < 65535 && p->W < 65535 &&
+                          !getenv("GANET_BWD_SCATTER_ATOMIC");
       if (!binned && hipMemsetAsync(gyb, 0, (size_t)M * N * 4, s) != hipSuccess) return GANET_ERR_HIP;
       BwdCtsArgs c;
       c.y = need_in ? yb : nullptr;
@@ -1155,7 +1187,10 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
       c.pW = p->pW;
       c.dH = p->dH;
       c.dW = p->dW;
+      c.geo_q = reinterpret_cast<unsigned *>(geo);
+      c.geo_f = reinterpret_cast<f32x2 *>(geo + ganet_align_up((size_t)pl.nb * T * HWo * 4, 256));
       if (binned) {
+        hipLaunchKernelGGL(cts_bwd_geo_kernel, dim3(blocks_for((long long)nimg * T * HWo)), dim3(256), 0, s, c);
         hipLaunchKernelGGL(cts_bwd_bin_kernel, dim3((unsigned)(nimg * T * parts), (unsigned)(p->Cout / 64)),
                            dim3(BIN_THREADS), 0, s, c, parts);
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
