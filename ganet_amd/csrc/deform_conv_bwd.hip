@@ -569,15 +569,14 @@ __global__ __launch_bounds__(256) void cts_bwd_geo_kernel(BwdCtsArgs a) {
 // whole image, so the form is used while an image has at most BIN_MAX_PARTS parts.  A list that
 // fills up (every sample of the image landing in one tile) makes the thread add its run itself
 // with LDS atomics.
-constexpr int BIN_Q = 128;
+constexpr int BIN_Q = 128;                // power of two <= 128: a list entry packs pixel << 7 | row
 constexpr int BIN_THREADS = 512;
-constexpr int BIN_CAP = 3968;             // list entries (tile + list = 78.5 KB: two workgroups per CU)
+constexpr int BIN_CAP = 2560;             // list entries of 8 bytes (tile + lists = 52.1 KB: three workgroups per CU)
 constexpr int BIN_MAX_PARTS = 512;         // 65536 pixels: still ahead of the atomics there (160x400: 2.38 vs 2.65 ms)
 
 __global__ __launch_bounds__(BIN_THREADS) void cts_bwd_bin_kernel(BwdCtsArgs a, int parts) {
   __shared__ __attribute__((aligned(16))) float s_tile[BIN_Q * 64];
-  __shared__ int s_ep[BIN_CAP];
-  __shared__ int s_eq[BIN_CAP];
+  __shared__ int s_ep[BIN_CAP];           // output pixel << 7 | tile row
   __shared__ float s_ew[BIN_CAP];
   __shared__ int s_cnt[BIN_THREADS / 32];
   const int tid = threadIdx.x, l = tid & 31;
@@ -630,8 +629,7 @@ __global__ __launch_bounds__(BIN_THREADS) void cts_bwd_bin_kernel(BwdCtsArgs a, 
           const int own = r & (NH - 1);          // the half wavefront that owns tile row r
           const int slot = atomicAdd(&s_cnt[own], 1);
           if (slot < LCAP) {
-            s_ep[own * LCAP + slot] = hw;
-            s_eq[own * LCAP + slot] = r;
+            s_ep[own * LCAP + slot] = hw << 7 | r;
             s_ew[own * LCAP + slot] = w * m;
           } else {
             // list full (far more samples than usual land in this tile): add the run here
@@ -658,10 +656,11 @@ __global__ __launch_bounds__(BIN_THREADS) void cts_bwd_bin_kernel(BwdCtsArgs a, 
     int r[DU];
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
-      const float *gp = gob + (size_t)s_ep[lb + e + u] * a.Cout + l;
+      const int pr = s_ep[lb + e + u];
+      const float *gp = gob + (size_t)(pr >> 7) * a.Cout + l;
       g0[u] = ldg_f32(gp);
       g1[u] = ldg_f32(gp + 32);
-      r[u] = s_eq[lb + e + u];
+      r[u] = pr & (BIN_Q - 1);
       w[u] = s_ew[lb + e + u];
     }
 #pragma unroll
@@ -671,9 +670,10 @@ __global__ __launch_bounds__(BIN_THREADS) void cts_bwd_bin_kernel(BwdCtsArgs a, 
     }
   }
   for (; e < cnt; ++e) {
-    const float *gp = gob + (size_t)s_ep[lb + e] * a.Cout + l;
+    const int pr = s_ep[lb + e];
+    const float *gp = gob + (size_t)(pr >> 7) * a.Cout + l;
     const float w = s_ew[lb + e];
-    const int r = s_eq[lb + e];
+    const int r = pr & (BIN_Q - 1);
     s_tile[r * 64 + l] += w * ldg_f32(gp);
     s_tile[r * 64 + l + 32] += w * ldg_f32(gp + 32);
   }

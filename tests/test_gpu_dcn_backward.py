@@ -116,7 +116,7 @@ def test_backward_direct_and_commuted_forms(case, modulated, algo):
 
 def test_commuted_form_when_every_sample_lands_on_one_spot():
     """All pixels and taps sample the same position: the LDS list of the binned grad_Y
-    kernel (3968 entries per 128-pixel tile) overflows and the inline path takes over."""
+    kernel (2560 entries per 128-pixel tile) overflows and the inline path takes over."""
     B, Cin, H, W, Cout, kH, kW = 1, 128, 20, 60, 64, 1, 3
     st, pad, dil = (1, 1), (0, 1), (1, 1)
     rng = np.random.default_rng(3)
@@ -153,6 +153,23 @@ def test_commuted_form_walks_the_batch_in_chunks(monkeypatch):
     close(gi, ref["grad_x"], "grad_x")
     close(goff, ref["grad_offset"], "grad_offset")
     close(gm, ref["grad_mask"], "grad_mask")
+    close(gw, ref["grad_weight"], "grad_weight")
+
+
+def test_commuted_form_on_a_large_map():
+    """80x200 (the C4 feature map): 125 tiles of 128 pixels per image and tap in the binned
+    grad_Y kernel, several 16-pixel steps per share in the weight-gradient kernel."""
+    case = (1, 128, 80, 200, 64, 1, 3, (1, 1), (0, 1), (1, 1), 1)
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, _, go = make(case, 41, False)
+    off *= 3.0                                   # samples reach a few rows away
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg)
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo = (torch.from_numpy(a).to(dev) for a in (x, off, w, go))
+    tx = tx.contiguous(memory_format=torch.channels_last)
+    gi, goff, _, gw, _ = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg, algo=2)
+    close(gi, ref["grad_x"], "grad_x")
+    close(goff, ref["grad_offset"], "grad_offset")
     close(gw, ref["grad_weight"], "grad_weight")
 
 
