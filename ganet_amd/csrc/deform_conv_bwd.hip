@@ -557,6 +557,85 @@ __global__ __launch_bounds__(256) void cts_bwd_geo_kernel(BwdCtsArgs a) {
   }
 }
 
+// Coordinate and mask gradients of one chunk when grad_Y is binned (the scatter is gone from
+// this pass, so the lanes are laid out for the gathers): 16 lanes per output pixel, 4 channels
+// = one 16-byte load per lane and corner, 4 pixels per wavefront, two taps' eight corner
+// loads in flight; geometry from cts_bwd_geo_kernel.  Same terms as get_coordinate_weight
+// (deform_conv_cuda_kernel.cu:146-188) through sum_o grad_out[o] * Y_t[corner][o].
+__global__ __launch_bounds__(256) void cts_bwd_coord_kernel(BwdCtsArgs a) {
+  const int tid = threadIdx.x, l = tid & 15;
+  const int HWo = a.Ho * a.Wo;
+  const int N = a.T * a.Cout;
+  const int cb = blockIdx.y;
+  const long long P = (long long)a.nimg * HWo;
+  const long long stride = (long long)gridDim.x * 16;
+  for (long long p = (long long)blockIdx.x * 16 + (tid >> 4); p < P; p += stride) {
+    const int bl = (int)(p / HWo);
+    const int hw = (int)(p - (long long)bl * HWo);
+    const int b = a.img0 + bl;
+    const u32x4 graw = ldg128(a.go + ((size_t)b * HWo + hw) * a.Cout + cb * 64 + 4 * l);
+    const f32x4 g = __builtin_bit_cast(f32x4, graw);
+    const float *ybase = a.y + (size_t)bl * a.H * a.W * N + cb * 64 + 4 * l;
+    auto tap = [&](int t, f32x4 (&v)[4], float &lh, float &lw, bool &in) {
+      const size_t k = ((size_t)bl * a.T + t) * HWo + hw;
+      const unsigned pk = a.geo_q[k];
+      const f32x2 fr = a.geo_f[k];
+      lh = fr[0];
+      lw = fr[1];
+      in = pk != ~0u;
+      const int h_low = (int)(pk >> 16) - 1, w_low = (int)(pk & 0xffffu) - 1;
+      const bool hl = in && h_low >= 0, hh = in && h_low + 1 <= a.H - 1;
+      const bool wl = w_low >= 0, wh = w_low + 1 <= a.W - 1;
+      const float *c1 = ybase + ((long long)h_low * a.W + w_low) * N + t * a.Cout;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      v[0] = __builtin_bit_cast(f32x4, hl && wl ? ldg128(c1) : z);
+      v[1] = __builtin_bit_cast(f32x4, hl && wh ? ldg128(c1 + N) : z);
+      v[2] = __builtin_bit_cast(f32x4, hh && wl ? ldg128(c1 + (size_t)a.W * N) : z);
+      v[3] = __builtin_bit_cast(f32x4, hh && wh ? ldg128(c1 + (size_t)a.W * N + N) : z);
+    };
+    auto finish = [&](int t, const f32x4 (&v)[4], float lh, float lw, bool in) {
+      const float hh = 1.f - lh, hw_ = 1.f - lw;
+      float sh = 0.f, sw = 0.f, sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sh += g[c] * (-hw_ * v[0][c] - lw * v[1][c] + hw_ * v[2][c] + lw * v[3][c]);
+        sw += g[c] * (-hh * v[0][c] + hh * v[1][c] - lh * v[2][c] + lh * v[3][c]);
+        sm += g[c] * (hh * hw_ * v[0][c] + hh * lw * v[1][c] + lh * hw_ * v[2][c] + lh * lw * v[3][c]);
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        sh += __shfl_xor(sh, o);
+        sw += __shfl_xor(sw, o);
+        sm += __shfl_xor(sm, o);
+      }
+      if (l == 0 && in) {
+        const float m = a.mask ? ldg_f32(a.mask + ((size_t)b * a.T + t) * HWo + hw) : 1.f;
+        float *q = a.goff + ((size_t)b * 2 * a.T + 2 * t) * HWo + hw;
+        unsafeAtomicAdd(q, m * sh);
+        unsafeAtomicAdd(q + HWo, m * sw);
+        if (a.gmask) unsafeAtomicAdd(a.gmask + ((size_t)b * a.T + t) * HWo + hw, sm);
+      }
+    };
+    int t = 0;
+    for (; t + 1 < a.T; t += 2) {
+      f32x4 va[4], vb[4];
+      float lha, lwa, lhb, lwb;
+      bool ina, inb;
+      tap(t, va, lha, lwa, ina);
+      tap(t + 1, vb, lhb, lwb, inb);
+      finish(t, va, lha, lwa, ina);
+      finish(t + 1, vb, lhb, lwb, inb);
+    }
+    if (t < a.T) {
+      f32x4 va[4];
+      float lha, lwa;
+      bool ina;
+      tap(t, va, lha, lwa, ina);
+      finish(t, va, lha, lwa, ina);
+    }
+  }
+}
+
 // grad_Y without global atomics.  The L2 retires about one float add per channel and clock
 // (tools/atomicbw.hip: 300 G adds/s whatever the locality), which is what the scatter above
 // runs at; LDS adds are two orders of magnitude cheaper.  One workgroup owns BIN_Q consecutive
@@ -1196,7 +1275,13 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
         c.gy = nullptr;
       }
-      if (need_in || !binned) {
+      if (binned && need_in && !getenv("GANET_BWD_COORD_32LANE")) {
+        long long nblk = ((long long)nimg * HWo + 15) / 16;
+        if (nblk > 256 * 32) nblk = 256 * 32;
+        hipLaunchKernelGGL(cts_bwd_coord_kernel, dim3((unsigned)nblk, (unsigned)(p->Cout / 64)), dim3(256),
+                           0, s, c);
+        if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+      } else if (need_in || !binned) {
         const long long groups = ((long long)nimg * HWo + 1) / 2;
         long long nblk = (groups + CS_WAVES - 1) / CS_WAVES;
         if (nblk > 256 * 16) nblk = 256 * 16;
