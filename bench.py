@@ -138,6 +138,38 @@ def cpu_baseline_and_parity(wl, dtype, d, hp, n_images, threads):
                 decode_images_per_s=(n / t_dec) if t_dec > 0 else None), parity
 
 
+def lfa_backward_side_measurement(dev, Cin, H, W, K, B=32, steps=20):
+    """SURVEY 8 row f4, outside the timed region and not part of `value`: all gradients of
+    the LFA's deform-conv (float32, channel-last, 32 images) through
+    ganet_deform_conv_backward.  Never lets a failure touch the bench line."""
+    try:
+        import torch
+        from ganet_amd import dcn, synth
+        x, off, w, _ = synth.lfa_inputs(B, Cin, H, W, K, Cout=64, seed=7)
+        tx, toff, tw = (torch.from_numpy(a).to(dev) for a in (x, off, w))
+        tx = tx.contiguous(memory_format=torch.channels_last)
+        pad = (0, (K - 1) // 2)
+        go = torch.randn_like(dcn.deform_conv_forward(tx, toff, tw, (1, 1), pad, (1, 1)))
+
+        def run():
+            dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), pad, (1, 1))
+
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        return {"what": "grad input+offset+weight, float32, channel-last, batch %d, %dx%d, K %d" % (B, H, W, K),
+                "ms": ms, "images_per_s": B / (ms * 1e-3), "steps": steps}
+    except Exception as exc:  # noqa: BLE001 - a side measurement must not break the line
+        return {"error": repr(exc)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +181,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-backward", action="store_true",
+                    help="skip the side measurement of the LFA backward (SURVEY 8 f4)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="profiling only")
     ap.add_argument("--algo", type=int, default=0,
@@ -385,6 +419,8 @@ def main():
                                                    threads)
             out["cpu_baseline"] = base
             out["parity"] = parity
+        if world == 1 and not args.no_backward:
+            out["lfa_backward"] = lfa_backward_side_measurement(dev, Cin, H, W, K)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

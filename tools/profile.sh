@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline $*"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-backward $*"
 run() { # name, rocprof args...
   local name=$1; shift
   timeout -s KILL 170 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o "$name" -- $BENCH > "$OUT/$name.log" 2>&1

@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/trace_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o t -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > "$OUT/log.txt" 2>&1 || { tail -5 "$OUT/log.txt"; exit 1; }
+timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o t -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-backward "$@" > "$OUT/log.txt" 2>&1 || { tail -5 "$OUT/log.txt"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv,glob,sys
 f=glob.glob(sys.argv[1]+"/**/*kernel_stats.csv",recursive=True)[0]
