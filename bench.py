@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup", type=int, default=300,
+                    help="untimed steps before the timed region, warm-up included (clock ramp)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "fp32"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
@@ -282,6 +284,13 @@ def main():
             if ev is not None:
                 ev[2].record()
 
+    # Device spin-up, before the W warm-up steps and reported as `spinup_steps`: the clocks of
+    # an idle MI355X ramp over the first ~100 steps of this workload (20 timed steps after 5
+    # warm-up steps read 0.346 ms, 200 after 20 read 0.310, anything after 300 reads 0.307),
+    # so a short run would time the ramp instead of the kernels.
+    spinup = max(0, args.spinup - args.warmup)
+    for _ in range(spinup):
+        one_step()
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
@@ -389,6 +398,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "spinup_steps": spinup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
