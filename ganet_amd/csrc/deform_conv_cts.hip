@@ -738,8 +738,21 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_split_wide_kernel
   // lane (i, h), registers 4g..4g+3 of slice sl hold outputs sl*32 + 8g + 4h + 0..3 of pixel i
   unsigned char *ys = s_y + wid * 32 * YROW;
   const int pc = lane & 7, rq = lane >> 3;       // 8 lanes x 16 B per 32-float row
+  // when accumulating, the destination's old values of slice sl + 1 are fetched while slice
+  // sl is staged and stored (one exposed read latency per wavefront instead of NS)
+  f32x4 old_v[4], next_v[4];
+  auto fetch_old = [&](int sl, f32x4 (&o)[4]) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const long long mr = m0 + ps * 8 + rq;
+      const u32x4 raw_o = ldg128(y + (mr < M ? mr : M - 1) * ldy + sl * 32 + pc * 4);
+      o[ps] = __builtin_bit_cast(f32x4, raw_o);
+    }
+  };
+  if (accumulate) fetch_old(0, old_v);
 #pragma unroll
   for (int sl = 0; sl < NS; ++sl) {
+    if (accumulate && sl + 1 < NS) fetch_old(sl + 1, next_v);
     float *yr = reinterpret_cast<float *>(ys + i * YROW) + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -756,9 +769,13 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, 2) void cts_gemm_split_wide_kernel
       const long long mr = m0 + rr;
       if (mr < M) {
         float *dst = y + mr * ldy + sl * 32 + pc * 4;
-        if (accumulate) v += *reinterpret_cast<const f32x4 *>(dst);
+        if (accumulate) v += old_v[ps];
         *reinterpret_cast<f32x4 *>(dst) = v;
       }
+    }
+    if (accumulate && sl + 1 < NS) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) old_v[ps] = next_v[ps];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
