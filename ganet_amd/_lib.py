@@ -29,6 +29,7 @@ EXPORTS = (
     "ganet_decode_workspace_bytes", "ganet_decode_batch", "ganet_group_batch",
     "ganet_decode_pack", "ganet_deform_conv_algorithm",
     "ganet_deform_conv_backward_workspace_bytes", "ganet_deform_conv_backward",
+    "ganet_decode_batch_noalloc",
 )
 
 
@@ -107,6 +108,10 @@ def lib():
             ctypes.c_void_p] * 3 + [ctypes.POINTER(DecodeParams),
                                     ctypes.POINTER(DecodeOut), ctypes.c_void_p,
                                     ctypes.c_size_t, ctypes.c_void_p]
+        L.ganet_decode_batch_noalloc.restype = ctypes.c_int
+        L.ganet_decode_batch_noalloc.argtypes = [
+            ctypes.c_void_p] * 3 + [ctypes.POINTER(DecodeParams),
+                                    ctypes.POINTER(DecodeOut), ctypes.c_void_p]
         L.ganet_group_batch.restype = ctypes.c_int
         L.ganet_group_batch.argtypes = [ctypes.POINTER(DecodeParams),
                                         ctypes.POINTER(DecodeOut), ctypes.c_void_p]

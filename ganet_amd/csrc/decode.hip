@@ -30,6 +30,8 @@
 
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -544,14 +546,13 @@ extern "C" size_t ganet_decode_workspace_bytes(const ganet_decode_params *p) {
   return ganet_align_up((size_t)p->B * nwords * sizeof(unsigned long long), 256);
 }
 
-extern "C" int ganet_decode_batch(const float *heat, const float *offset,
-                                  const float *error,
-                                  const ganet_decode_params *p,
-                                  const ganet_decode_out *out, void *workspace,
-                                  size_t workspace_bytes,
-                                  ganet_stream_t stream) {
-  if (!heat || !offset || !error || !p || !out || !workspace)
-    return GANET_ERR_NULL;
+namespace {
+
+// shared by ganet_decode_batch (bitmap in the caller's workspace) and
+// ganet_decode_batch_noalloc (bitmap in the library's static device array)
+int decode_batch_check(const float *heat, const float *offset, const float *error,
+                       const ganet_decode_params *p, const ganet_decode_out *out) {
+  if (!heat || !offset || !error || !p || !out) return GANET_ERR_NULL;
   if (!out->counts || !out->centers_xy || !out->center_gid || !out->kpt_xy ||
       !out->kpt_align || !out->kpt_root || !out->kpt_gid ||
       !out->group_center || !out->group_count)
@@ -564,13 +565,14 @@ extern "C" int ganet_decode_batch(const float *heat, const float *offset,
     return GANET_ERR_UNSUPPORTED;
   if (p->max_centers > kMaxCenters) return GANET_ERR_UNSUPPORTED;
   if (p->B > 65535) return GANET_ERR_UNSUPPORTED;  // grid.y of the mask kernel
-  if (workspace_bytes < ganet_decode_workspace_bytes(p))
-    return GANET_ERR_WORKSPACE;
+  return GANET_OK;
+}
 
-  hipStream_t s = static_cast<hipStream_t>(stream);
+int decode_batch_launch(const float *heat, const float *offset, const float *error,
+                        const ganet_decode_params *p, const ganet_decode_out *out,
+                        unsigned long long *kmask, hipStream_t s) {
   const int HW = p->H * p->W;
   const int nwords = (HW + 63) / 64;
-  unsigned long long *kmask = static_cast<unsigned long long *>(workspace);
 
   const bool fused_mask = nwords <= kFusedMaskWords;
   if (!fused_mask) {
@@ -599,6 +601,70 @@ extern "C" int ganet_decode_batch(const float *heat, const float *offset,
   a.out = *out;
   hipLaunchKernelGGL(decode_group_kernel<true>, dim3(p->B), dim3(kBlock), 0, s, a);
   return ganet_check_launch();
+}
+
+// ---- the keypoint bitmap of ganet_decode_batch_noalloc --------------------------------
+// One copy per GPU, held until the process ends.  `g_decode_scratch` is a host-side
+// stand-in, not a device address: host code only ever uses the per-device address that
+// hipGetSymbolAddress returned (decode_scratch_ptr).
+constexpr size_t kStaticScratchBytes = GANET_DECODE_NOALLOC_MAX_BYTES;
+static __device__ __align__(256) unsigned long long
+    g_decode_scratch[kStaticScratchBytes / sizeof(unsigned long long)];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned long long *g_scratch_ptr[kMaxDevices] = {};
+
+// address of the current device's copy of g_decode_scratch (looked up once per device)
+int decode_scratch_ptr(unsigned long long **ptr) {
+  int dev = -1;
+  GANET_RETURN_IF_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return GANET_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void *q = nullptr;
+    GANET_RETURN_IF_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(g_decode_scratch)));
+    if (!q) return GANET_ERR_HIP;
+    g_scratch_ptr[dev] = static_cast<unsigned long long *>(q);
+  }
+  *ptr = g_scratch_ptr[dev];
+  return GANET_OK;
+}
+
+}  // namespace
+
+extern "C" int ganet_decode_batch(const float *heat, const float *offset,
+                                  const float *error,
+                                  const ganet_decode_params *p,
+                                  const ganet_decode_out *out, void *workspace,
+                                  size_t workspace_bytes,
+                                  ganet_stream_t stream) {
+  if (!workspace) return GANET_ERR_NULL;
+  const int rc = decode_batch_check(heat, offset, error, p, out);
+  if (rc != GANET_OK) return rc;
+  if (workspace_bytes < ganet_decode_workspace_bytes(p))
+    return GANET_ERR_WORKSPACE;
+  return decode_batch_launch(heat, offset, error, p, out,
+                             static_cast<unsigned long long *>(workspace),
+                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ganet_decode_batch_noalloc(const float *heat, const float *offset,
+                                          const float *error,
+                                          const ganet_decode_params *p,
+                                          const ganet_decode_out *out,
+                                          ganet_stream_t stream) {
+  const int rc = decode_batch_check(heat, offset, error, p, out);
+  if (rc != GANET_OK) return rc;
+  // the bitmap must fit the static array: B * ceil(H*W/64) words
+  if (ganet_decode_workspace_bytes(p) > kStaticScratchBytes) return GANET_ERR_WORKSPACE;
+  unsigned long long *kmask = nullptr;
+  const int rp = decode_scratch_ptr(&kmask);
+  if (rp != GANET_OK) return rp;
+  // every word of the bitmap the group kernel reads is written by the mask kernel of the
+  // same call, so nothing has to start at zero
+  return decode_batch_launch(heat, offset, error, p, out, kmask,
+                             static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ganet_group_batch(const ganet_decode_params *p,

@@ -9,8 +9,9 @@
  * pointer is caller-owned; the library never allocates or frees device memory
  * in these calls (scratch comes in through the `workspace` arguments), never
  * synchronises with the host, and enqueues only on the stream it is given.
- * All entry points are re-entrant and hold no mutable global state; call them
- * from one host thread per GPU with that GPU current.
+ * All entry points are re-entrant; the only state the library keeps between calls
+ * is the per-GPU address of the static scratch array of ganet_decode_batch_noalloc.
+ * Call them from one host thread per GPU with that GPU current.
  *
  * Citations are file:line in the reference tree (Wolfwjs/GANet).
  */
@@ -249,6 +250,21 @@ int ganet_decode_batch(const float *heat, const float *offset,
                        const float *error, const ganet_decode_params *p,
                        const ganet_decode_out *out, void *workspace,
                        size_t workspace_bytes, ganet_stream_t stream);
+
+/* The same call for callers that cannot allocate device memory or carry a workspace
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * No counterpart in the reference.  The keypoint bitmap that `workspace` holds in
+ * ganet_decode_batch lives in a static device array of the library instead
+ * (GANET_DECODE_NOALLOC_MAX_BYTES per GPU, held until the process ends); the call
+ * allocates and frees nothing.  Needs B * ceil(H*W/64) * 8 bytes (rounded up to 256)
+ * <= GANET_DECODE_NOALLOC_MAX_BYTES, else GANET_ERR_WORKSPACE.  Every call on one GPU
+ * shares that GPU's array: calls that overlap on one GPU (two streams, two threads)
+ * race; run them one after the other on one stream.  Results are identical to
+ * ganet_decode_batch. */
+#define GANET_DECODE_NOALLOC_MAX_BYTES (4u << 20)
+int ganet_decode_batch_noalloc(const float *heat, const float *offset,
+                               const float *error, const ganet_decode_params *p,
+                               const ganet_decode_out *out, ganet_stream_t stream);
 
 /* Grouping only, on lists that already sit in `out` on the device (written by
  * an earlier ganet_decode_batch with flags bit0, or uploaded by the caller):
