@@ -19,7 +19,7 @@ COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17",
           "-Wall", "-Wno-unused-function"]
 # decode.hip must round like numpy / CPython: no fused multiply-add contraction.
 PER_FILE = {"decode.hip": ["-ffp-contract=off"]}
-SOURCES = ["api.hip", "decode.hip", "deform_conv.hip", "deform_conv_cts.hip",
+SOURCES = ["api.hip", "decode.hip", "deform_conv.hip", "deform_conv_cts.hip", "deform_conv_stream.hip",
            "deform_conv_bwd.hip"]
 
 
@@ -30,6 +30,9 @@ def _newer(a, b):
 def build_lib(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DGANET_ABLATE"] if os.environ.get("GANET_ABLATE") else []  # profiling build
+    if os.environ.get("GANET_STREAM_DEBUG"):
+        extra.append("-DGANET_STREAM_DEBUG")
+        extra += os.environ.get("GANET_STREAM_DEFS", "").split()
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(ROOT, "include", "ganet_hip.h"), os.path.join(CSRC, "dcn_device.h"),
                os.path.join(CSRC, "common.h")]

@@ -127,6 +127,14 @@ int cts_forward(const void *xh, const float *offset, const float *mask, const vo
                 const void *bias, void *out, const ganet_dcn_params *p, int ta, int kc,
                 int Cp, int CoutP, int Ho, int Wo, void *ybuf, hipStream_t s);
 
+// the same algorithm as one persistent launch (csrc/deform_conv_stream.hip): producer
+// workgroups contract, consumer workgroups sample, Y travels through a cache-resident ring
+bool stream_applicable(const ganet_dcn_params *p, int ta, int Cp, int CoutP, int Ho, int Wo);
+size_t stream_workspace_bytes(const ganet_dcn_params *p, int CoutP);
+int stream_forward(const void *xh, const float *offset, const float *mask, const void *wq,
+                   const void *bias, void *out, const ganet_dcn_params *p, int ta, int Cp,
+                   int CoutP, void *ws, hipStream_t s);
+
 // exact-float32 GEMM of the same file, for the backward (csrc/deform_conv_bwd.hip)
 int cts_gemm_f32(const float *x, const float *wq, float *y, long long M, int K, int N,
                  hipStream_t s);

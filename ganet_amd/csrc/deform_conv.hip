@@ -586,6 +586,7 @@ struct Plan {
   bool copy_x;   // a channel-last (and/or converted, padded) copy of x is made
   bool cts;      // contract-then-sample path (deform_conv_cts.hip)
   bool split;    // ... with float32 tensors contracted as three bf16 passes
+  bool stream;   // ... as one persistent producer/consumer launch (deform_conv_stream.hip)
   size_t xh_bytes, wp_bytes, y_bytes;
 };
 
@@ -660,9 +661,14 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
   // Sampling and contraction commute; contract first when that shrinks the rows
   // that have to be gathered and blended (Cout < Cin, as in the LFA).
   pl->cts = cts_applicable(p, pl->Cp, pl->CoutP) && p->algo != 1;
+  if (p->algo < 0 || p->algo > 3) return GANET_ERR_BAD_SHAPE;
   if (p->algo == 2 && !pl->cts) return GANET_ERR_UNSUPPORTED;
   pl->split = pl->cts && pl->ta == GANET_F32 && cts_split(p, pl->Cp);
-  pl->y_bytes = pl->cts ? cts_y_bytes(p, pl->CoutP, pl->ta) : 0;
+  pl->stream = pl->cts && p->algo == 3 &&
+               stream_applicable(p, pl->ta, pl->Cp, pl->CoutP, pl->Ho, pl->Wo);
+  if (p->algo == 3 && !pl->stream) return GANET_ERR_UNSUPPORTED;
+  pl->y_bytes = pl->stream ? stream_workspace_bytes(p, pl->CoutP)
+                           : (pl->cts ? cts_y_bytes(p, pl->CoutP, pl->ta) : 0);
   return GANET_OK;
 }
 
@@ -743,7 +749,7 @@ extern "C" size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p) {
 extern "C" int ganet_deform_conv_algorithm(const ganet_dcn_params *p) {
   Plan pl;
   if (!p || make_plan(p, &pl) != GANET_OK) return 0;
-  return pl.cts ? 2 : 1;
+  return pl.stream ? 3 : (pl.cts ? 2 : 1);
 }
 
 extern "C" size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p) {
@@ -826,6 +832,9 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
       pack_weight_dispatch(p, pl, weight, ws + pl.xh_bytes + pl.y_bytes, s) != GANET_OK)
     return GANET_ERR_HIP;
 
+  if (pl.stream)
+    return stream_forward(pl.copy_x ? xh : x, offset, mask, wp, bias, out, p, pl.ta, pl.Cp,
+                          pl.CoutP, ybuf, s);
   if (pl.cts)
     return cts_forward(pl.copy_x ? xh : x, offset, mask, wp, bias, out, p, pl.ta, pl.kc,
                        pl.Cp, pl.CoutP, pl.Ho, pl.Wo, ybuf, s);

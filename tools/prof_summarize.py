@@ -10,12 +10,12 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("dcn_fused_kernel", "cts_gemm_split_kernel", "cts_gemm_ov_kernel", "cts_gemm_kernel", "pack_weight_split_kernel", "cts_sample_kernel",
+    for key in ("lfa_stream_kernel", "dcn_fused_kernel", "cts_gemm_split_kernel", "cts_gemm_ov_kernel", "cts_gemm_kernel", "pack_weight_split_kernel", "cts_sample_kernel",
                 "decode_mask_kernel", "decode_group_kernel", "decode_pack_kernel",
                 "nchw_to_nhwc_kernel", "nhwc_repack_kernel", "pack_weight_kernel"):
         if key in name:
             tail = ""
-            if "dcn_fused" in name or "cts_" in name:
+            if "dcn_fused" in name or "cts_" in name or "lfa_stream" in name:
                 tail = "<" + ("bf16" if "bf16" in name else "f16" if "DF16" in name else "f32") + ">"
             return key + tail
     return name.split("<")[0][:60]
