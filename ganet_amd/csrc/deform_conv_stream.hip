@@ -6,17 +6,18 @@
 // (mmdet/ops/dcn/src/cuda/deform_conv_cuda.cpp:222-236) with 2 launches per chunk of the
 // batch, 8 per LFA call at 128 images: every launch ramps up and drains on its own, the
 // matrix cores idle while the sampling kernel runs and the vector units idle during the
-// GEMM.  Here one workgroup per CU stays resident for the whole call and every wavefront
-// works in both roles:
+// GEMM.  Here one workgroup per CU stays resident for the whole call; its first waves (one
+// per SIMD) produce Y, the others sample it:
 //
-//   produce   one item = 64 pixels of one image x the CU's share of the T*Cout columns of Y.
+//   produce   one item = 128 pixels of one image x the CU's share of the T*Cout columns of Y.
 //             The share's weights sit in LDS for the whole launch (no slice staging, no
 //             barrier): with T*Cout*Cin*2 bytes over the LDS size the columns are split
 //             over `nsplit` kinds of workgroup (224 of 448 columns each at the LFA shape).
 //             x goes from memory straight into MFMA operands, the weight rows are read
 //             through a permutation that leaves 16 consecutive outputs of one pixel in
-//             every lane's accumulator, so Y leaves the registers as 16-byte stores.
-//   consume   one item = 32 output pixels: the pixel-group loop of cts_sample_kernel
+//             every lane's accumulator; two 32-column blocks are parked in a wave-private
+//             LDS tile and leave as whole 128-byte lines.
+//   consume   one item = 64 output pixels: the pixel-group loop of cts_sample_kernel
 //             (8 lanes x 16 B per pixel, 4 buffer loads per lane and tap, a corner outside
 //             the map reads 0 through the buffer bounds check).
 //
@@ -28,10 +29,9 @@
 // of its 8 pixels first, knows from them the last band it reads, and loads only after every
 // band up to that one has its full count.  No line of Y is loaded before it is complete, so
 // no L1 holds an old copy of it within the launch.  Both kinds of item are claimed in order
-// from counters.  A wave whose pixels are not ready yet produces instead of waiting, and
-// producing never waits, so every claimed item gets done whatever the placement.  Half the
-// waves prefer producing, but only up to `lag_px` pixels ahead of the consumers: Y should
-// still be in L2 when it is read.
+// from counters.  Producing never waits and every resident workgroup has producing waves, so
+// every band a sampling wave waits for gets done whatever the placement; a producing wave
+// samples once no item of its kind is left.
 // Nothing depends on dispatch order.  What the launch needs is an XCD that holds workgroups
 // of every kind at once: owner words are only taken by such an XCD.  Every wait is bounded
 // (STREAM_TIMEOUT_TICKS); a timeout sets ctl[CTL_ERROR] and every wave leaves.
@@ -52,12 +52,18 @@ namespace {
 #endif
 constexpr int FW = GANET_STREAM_WAVES;   // waves per workgroup, one workgroup per CU
 constexpr int FNT = FW * 64;
-constexpr int PITEM = 64;                // pixels per producer item
-constexpr int CITEM = 32;                // pixels per consumer item
+constexpr int PITEM = 128;               // pixels per producer item
+constexpr int CITEM = 64;                // pixels per consumer item
 constexpr int CSTEP = 8;                 // pixels per consumer step (8 lanes each)
 constexpr int BANDPX = 256;              // pixels per completion counter
 constexpr int NQ = 8;                    // queues (one per XCD)
 constexpr int SMEM_BYTES = 160 * 1024 - 256;
+constexpr int STAGE_ROW = 128 + 16;      // bytes per pixel row of a producing wave's LDS tile
+constexpr int STAGE_BYTES = 32 * STAGE_ROW;
+#ifndef GANET_STREAM_PROD_WAVES
+#define GANET_STREAM_PROD_WAVES 4
+#endif
+constexpr int STREAM_PROD_WAVES = GANET_STREAM_PROD_WAVES;   // producing waves per workgroup
 constexpr unsigned long long STREAM_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz clock
 
 static_assert(BANDPX % PITEM == 0, "a producer item lies in one band");
@@ -91,8 +97,7 @@ struct StreamArgs {
   int nsplit, ncols;    // kinds of workgroup, columns of Y per kind
   int pipi, cipi;       // producer / consumer items per image
   int nbands;           // bands per image
-  int lag_px;           // how far producing runs ahead of consuming by preference
-  int prod_waves;       // waves 0..prod_waves-1 prefer producing
+  int prod_waves;       // waves 0..prod_waves-1 produce
   int whole_image;      // debug: consumers wait for the whole image
   int debug;            // timing experiments: bit0 produce nothing, bit1 sample nothing, bit2 no readiness wait
 };
@@ -154,10 +159,12 @@ __device__ __forceinline__ unsigned band_target(const StreamArgs &a, int band) {
 // MFMA rows = outputs (weights from LDS), columns = pixels (x from memory).  Lane i reads
 // weight row perm(i) = 16*((i>>2)&1) + 4*(i>>3) + (i&3) of the 32-column block: the
 // accumulator registers 4g+e of lane (i, h) then hold outputs 16h + 4g + e of pixel i,
-// 32 contiguous bytes of Y.
+// 32 contiguous bytes of Y.  Two blocks (64 columns = one 128-byte line per pixel) are parked
+// in the wave's LDS tile and stored as whole lines, 8 lanes x 16 B each.
 template <typename TA, int KH>
 __device__ __forceinline__ void produce_item(const StreamArgs &a, int img, int item, int kind,
-                                             const unsigned char *s_wt, int lane STAMP_ARGS) {
+                                             const unsigned char *s_wt, unsigned char *stage,
+                                             int lane STAMP_ARGS) {
   constexpr int EPL = 8;
   constexpr int NQF = KH / 16;
   constexpr int LDB = KH + EPL;               // +16 B: conflict-free ds_read_b128
@@ -169,20 +176,20 @@ __device__ __forceinline__ void produce_item(const StreamArgs &a, int img, int i
   const int perm = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
   const TA *wrow = reinterpret_cast<const TA *>(s_wt) + perm * LDB + h * EPL;
   const TA *x = static_cast<const TA *>(a.x) + (size_t)img * HW * a.Cp;
-  unsigned char *y = static_cast<unsigned char *>(a.y) + (size_t)img * HW * N * 2;
+  unsigned char *y = static_cast<unsigned char *>(a.y) + (size_t)img * HW * N * 2 +
+                     (size_t)kind * a.ncols * 2;
+  unsigned char *st_w = stage + i * STAGE_ROW + h * 32;
 
 #pragma unroll 1
   for (int pb = 0; pb < PITEM / 32; ++pb) {
     const int m0 = item * PITEM + pb * 32;
     if (m0 >= HW || (a.debug & 1)) break;
     const int r = m0 + i;
-    const bool valid = r < HW;
-    const TA *xrow = x + (size_t)(valid ? r : HW - 1) * a.Cp + h * EPL;
+    const TA *xrow = x + (size_t)(r < HW ? r : HW - 1) * a.Cp + h * EPL;
     frag_t fa[NQF];
 #pragma unroll
     for (int q = 0; q < NQF; ++q)
       fa[q] = __builtin_bit_cast(frag_t, ldg128(xrow + q * 2 * EPL));
-    unsigned char *yp = y + ((size_t)r * N + kind * a.ncols + 16 * h) * 2;
 #ifdef GANET_STREAM_DEBUG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(1);
@@ -204,9 +211,28 @@ __device__ __forceinline__ void produce_item(const StreamArgs &a, int img, int i
       u32x4 lo, hi;
       __builtin_memcpy(&lo, v, 16);
       __builtin_memcpy(&hi, v + 8, 16);
-      if (valid) {
-        stg128(yp + cb * 64, lo);
-        stg128(yp + cb * 64 + 16, hi);
+      *reinterpret_cast<u32x4 *>(st_w + (cb & 1) * 64) = lo;
+      *reinterpret_cast<u32x4 *>(st_w + (cb & 1) * 64 + 16) = hi;
+      if (cb & 1) {
+        wave_sync_lds();
+        const int pc = lane & 7, rq = lane >> 3;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int rr = ps * 8 + rq;
+          const u32x4 t = *reinterpret_cast<const u32x4 *>(stage + rr * STAGE_ROW + pc * 16);
+          if (m0 + rr < HW) stg128(y + ((size_t)(m0 + rr) * N + (cb - 1) * 32) * 2 + pc * 16, t);
+        }
+        wave_sync_lds();
+      } else if (cb == ncb - 1) {   // an odd block count ends on half a line per pixel
+        wave_sync_lds();
+        const int pc = lane & 3, rq = lane >> 2;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int rr = ps * 16 + rq;
+          const u32x4 t = *reinterpret_cast<const u32x4 *>(stage + rr * STAGE_ROW + pc * 16);
+          if (m0 + rr < HW) stg128(y + ((size_t)(m0 + rr) * N + cb * 32) * 2 + pc * 16, t);
+        }
+        wave_sync_lds();
       }
     }
     STAMP(2);
@@ -318,18 +344,29 @@ __device__ __forceinline__ void consume_sample(const StreamArgs &a, int img, int
   for (int j = 0; j < NACC; ++j) acc[j] = f32x2{0.f, 0.f};
   const unsigned int *to = s_off + pj * a.T * 4;
   const float *tw = s_w + pj * a.T * 4;
-#pragma unroll 2
-  for (int t = 0; t < a.T; ++t) {
-    const uint4 cx = *reinterpret_cast<const uint4 *>(to + t * 4);
-    const float4 w = *reinterpret_cast<const float4 *>(tw + t * 4);
-    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.x + lane_off, 0, 0);
-    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.y + lane_off, 0, 0);
-    const u32x4 v3 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.z + lane_off, 0, 0);
-    const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.w + lane_off, 0, 0);
-    sacc_piece<TY>(v1, w.x, acc);
-    sacc_piece<TY>(v2, w.y, acc);
-    sacc_piece<TY>(v3, w.z, acc);
-    sacc_piece<TY>(v4, w.w, acc);
+  for (int t0 = 0; t0 < a.T; t0 += 4) {
+    // the loads of four taps (16 x 16 B per lane) go out before the first one is used
+    u32x4 v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (t0 + j < a.T) {
+        const uint4 cx = *reinterpret_cast<const uint4 *>(to + (t0 + j) * 4);
+        v[j][0] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.x + lane_off, 0, 0);
+        v[j][1] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.y + lane_off, 0, 0);
+        v[j][2] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.z + lane_off, 0, 0);
+        v[j][3] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, cx.w + lane_off, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (t0 + j < a.T) {
+        const float4 w = *reinterpret_cast<const float4 *>(tw + (t0 + j) * 4);
+        sacc_piece<TY>(v[j][0], w.x, acc);
+        sacc_piece<TY>(v[j][1], w.y, acc);
+        sacc_piece<TY>(v[j][2], w.z, acc);
+        sacc_piece<TY>(v[j][3], w.w, acc);
+      }
+    }
   }
   wave_sync_lds();   // the table is free again
 
@@ -374,9 +411,10 @@ __device__ __forceinline__ void consume_sample(const StreamArgs &a, int img, int
 
 __device__ __forceinline__ int queue_images(int B, int q) { return q < B ? (B - q + NQ - 1) / NQ : 0; }
 
-// one lane: a queue this XCD serves that still has unclaimed items, or -1 when there is
-// nothing left for it (or the launch has failed).
-__device__ int find_queue(const StreamArgs &a, unsigned xcc, int kind) {
+// one lane: a queue this XCD serves that still has unclaimed items of the wave's role
+// (producer items of its kind, or consumer items), or -1 when there is none left (or the
+// launch has failed).
+__device__ int find_queue(const StreamArgs &a, unsigned xcc, int kind, bool producing) {
   unsigned int *ctl = a.ctl;
   const unsigned me = xcc + 1u;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -396,8 +434,8 @@ __device__ int find_queue(const StreamArgs &a, unsigned xcc, int kind) {
       }
       if (o != me) continue;
       const unsigned int *qw = ctl + CTL_QUEUE + q * Q_WORDS;
-      if (flag_load(&qw[Q_CONS]) < (unsigned)(nimg * a.cipi) ||
-          flag_load(&qw[Q_PROD + kind * CTL_LINE]) < (unsigned)(nimg * a.pipi))
+      if (producing ? flag_load(&qw[Q_PROD + kind * CTL_LINE]) < (unsigned)(nimg * a.pipi)
+                    : flag_load(&qw[Q_CONS]) < (unsigned)(nimg * a.cipi))
         return q;
     }
     if (!pending) return -1;
@@ -446,150 +484,107 @@ __global__ __launch_bounds__(FNT, FW / 4) void lfa_stream_kernel(StreamArgs a) {
     }
   }
   __syncthreads();
+  // LDS beyond the weights: an output tile per producing wave (it doubles as that wave's
+  // corner table once it samples), a corner table per sampling wave
   const int wt_bytes = a.ncols * LDB * 2;
-  unsigned int *s_off = reinterpret_cast<unsigned int *>(smem + wt_bytes + wid * (CSTEP * a.T * 32));
+  const int tab_bytes = CSTEP * a.T * 32;
+  const int preg = tab_bytes > STAGE_BYTES ? tab_bytes : STAGE_BYTES;
+  unsigned char *region = smem + wt_bytes +
+                          (wid < a.prod_waves ? wid * preg
+                                              : a.prod_waves * preg + (wid - a.prod_waves) * tab_bytes);
+  unsigned int *s_off = reinterpret_cast<unsigned int *>(region);
   float *s_w = reinterpret_cast<float *>(s_off + CSTEP * a.T * 4);
 
   const int HW = a.H * a.W;
-  const bool prefer_prod = wid < a.prod_waves;
+  bool producing = wid < a.prod_waves;
   int q = -1, ptotal = 0, ctotal = 0;
   unsigned int *qw = ctl;
-  int c_item = -1, c_step = 0, c_img = 0, c_p0 = 0, c_need = -1;
-  bool tab_valid = false;
   int wm_img = -1, wm = 0;
-  unsigned pn_seen = 0;
-  unsigned spins = 0;
-  unsigned long long t0 = 0;
+  bool failed = false;
   STAMP_DECL;
 
-  for (;;) {
+  while (!failed) {
     if (q < 0) {
       int nq = -1;
-      if (lane == 0) nq = find_queue(a, xcc, kind);
+      if (lane == 0) nq = find_queue(a, xcc, kind, producing);
       q = __builtin_amdgcn_readfirstlane(nq);
-      if (q < 0) break;
+      if (q < 0) {
+        if (!producing) break;
+        producing = false;   // no item of this kind is left anywhere: sample from now on
+        continue;
+      }
       const int nimg = queue_images(a.B, q);
       ptotal = nimg * a.pipi;
       ctotal = nimg * a.cipi;
       qw = ctl + CTL_QUEUE + q * Q_WORDS;
-      pn_seen = 0;
     }
-
-    bool blocked = false, tried_cons = false;
-    if (c_item >= 0) {
-      // ---- a step of the consumer item this wave holds
-      if (!tab_valid) {
-        c_p0 = (c_item % a.cipi) * CITEM + c_step * CSTEP;
-        STAMP(0);
-        c_need = consume_corners(a, c_img, c_p0, lane, s_off, s_w);
-        if (a.whole_image && c_need >= 0) c_need = a.nbands - 1;
-        tab_valid = true;
-        STAMP(4);
-      }
-      if (wm_img != c_img) {
-        wm_img = c_img;
-        wm = 0;
-      }
-      if (__any(c_need >= wm)) {
-        // one round trip: the counters of bands wm .. wm + 63, one per lane
-        const int b = wm + lane;
-        bool open = false;
-        if (b < a.nbands)
-          open = flag_load(&cnt[(size_t)c_img * a.nbands + b]) < band_target(a, b);
-        const unsigned long long m = __ballot(open);
-        wm += m ? (int)__builtin_ctzll(m) : min(64, a.nbands - wm);
-        STAMP(5);
-      }
-      if (!__any(c_need >= wm) || (a.debug & 4)) {
-        asm volatile("" ::: "memory");
-        if (!(a.debug & 2)) consume_sample<TA, TO>(a, c_img, c_p0, lane, s_off, s_w);
-#ifdef GANET_STREAM_DEBUG
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(6);
-#endif
-        tab_valid = false;
-        spins = 0;
-        ++c_step;
-        if (c_step == CITEM / CSTEP || (c_item % a.cipi) * CITEM + c_step * CSTEP >= HW)
-          c_item = -1;
-        continue;
-      }
-      blocked = true;   // its Y is not complete: produce meanwhile
-    } else {
-      // ---- choose: producing waves consume once they are lag_px ahead
-      int ci = -1;
-      if (lane == 0) {
-        bool cons = true;
-        if (prefer_prod) {
-          const unsigned cn = flag_load(&qw[Q_CONS]);
-          if ((long long)pn_seen * PITEM - (long long)cn * CITEM < (long long)a.lag_px) cons = false;
-        }
-        if (cons) {
-          const unsigned c = flag_add(&qw[Q_CONS], 1u);
-          ci = c < (unsigned)ctotal ? (int)c : -2;
-        }
-      }
-      ci = __builtin_amdgcn_readfirstlane(ci);
-      tried_cons = ci != -1;
-      if (ci >= 0) {
-        c_item = ci;
-        c_step = 0;
-        c_img = q + NQ * (ci / a.cipi);
-        tab_valid = false;
-        continue;
-      }
-    }
-
-    // ---- produce one item
     int k = -1;
     if (lane == 0) {
-      const unsigned kk = flag_add(&qw[Q_PROD + kind * CTL_LINE], 1u);
-      pn_seen = kk;
-      k = kk < (unsigned)ptotal ? (int)kk : -1;
+      const unsigned kk = flag_add(&qw[producing ? Q_PROD + kind * CTL_LINE : Q_CONS], 1u);
+      k = kk < (unsigned)(producing ? ptotal : ctotal) ? (int)kk : -1;
     }
     k = __builtin_amdgcn_readfirstlane(k);
-    pn_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)pn_seen);
-    if (k >= 0) {
-      STAMP(0);
-      produce_item<TA, KH>(a, q + NQ * (k / a.pipi), k % a.pipi, kind, smem, lane STAMP_PASS);
-      spins = 0;
+    if (k < 0) {
+      q = -1;
       continue;
     }
-    if (blocked) {
-      // every item of this kind is claimed; the waves that hold them never wait
-      if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
-      STAMP(0);
-      __builtin_amdgcn_s_sleep(16);
-      STAMP(7);
-      if ((++spins & 63) == 0) {
-        int stop = 0;
-        if (lane == 0) {
-          if (flag_load(&ctl[CTL_ERROR]) != 0) stop = 1;
-          else if (__builtin_amdgcn_s_memrealtime() - t0 > STREAM_TIMEOUT_TICKS) {
-            flag_store(&ctl[CTL_ERROR], 1u);
-            stop = 1;
+    STAMP(0);
+    if (producing) {
+      produce_item<TA, KH>(a, q + NQ * (k / a.pipi), k % a.pipi, kind, smem, region, lane STAMP_PASS);
+      continue;
+    }
+
+    // ---- a consumer item: CITEM pixels in steps of CSTEP
+    const int c_img = q + NQ * (k / a.cipi);
+    const int c_px = (k % a.cipi) * CITEM;
+    if (wm_img != c_img) {
+      wm_img = c_img;
+      wm = 0;
+    }
+    for (int st = 0; st < CITEM / CSTEP && !failed; ++st) {
+      const int p0 = c_px + st * CSTEP;
+      if (p0 >= HW) break;
+      int need = consume_corners(a, c_img, p0, lane, s_off, s_w);
+      if (a.whole_image && need >= 0) need = a.nbands - 1;
+      STAMP(4);
+      if (!(a.debug & 4)) {
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        while (__any(need >= wm)) {
+          // one round trip: the counters of bands wm .. wm + 63, one per lane
+          const int b = wm + lane;
+          bool open = false;
+          if (b < a.nbands)
+            open = flag_load(&cnt[(size_t)c_img * a.nbands + b]) < band_target(a, b);
+          const unsigned long long m = __ballot(open);
+          wm += m ? (int)__builtin_ctzll(m) : min(64, a.nbands - wm);
+          if (!__any(need >= wm)) break;
+          // the band is claimed by a producing wave or will be: those never wait
+          if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
+          __builtin_amdgcn_s_sleep(32);
+          if ((++spins & 63) == 0) {
+            int stop = 0;
+            if (lane == 0) {
+              if (flag_load(&ctl[CTL_ERROR]) != 0) stop = 1;
+              else if (__builtin_amdgcn_s_memrealtime() - t0 > STREAM_TIMEOUT_TICKS) {
+                flag_store(&ctl[CTL_ERROR], 1u);
+                stop = 1;
+              }
+            }
+            if (__builtin_amdgcn_readfirstlane(stop)) failed = true;
+            if (failed) break;
           }
         }
-        if (__builtin_amdgcn_readfirstlane(stop)) break;
       }
-      continue;
+      STAMP(5);
+      if (failed) break;
+      asm volatile("" ::: "memory");
+      if (!(a.debug & 2)) consume_sample<TA, TO>(a, c_img, p0, lane, s_off, s_w);
+#ifdef GANET_STREAM_DEBUG
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(6);
+#endif
     }
-    if (!tried_cons) {
-      int ci = -1;
-      if (lane == 0) {
-        const unsigned c = flag_add(&qw[Q_CONS], 1u);
-        ci = c < (unsigned)ctotal ? (int)c : -1;
-      }
-      ci = __builtin_amdgcn_readfirstlane(ci);
-      if (ci >= 0) {
-        c_item = ci;
-        c_step = 0;
-        c_img = q + NQ * (ci / a.cipi);
-        tab_valid = false;
-        continue;
-      }
-    }
-    q = -1;   // nothing left to claim in this queue
   }
 #ifdef GANET_STREAM_DEBUG
   STAMP(0);
@@ -610,7 +605,10 @@ int stream_nsplit(int T, int CoutP, int Cp) {
   const int N = T * CoutP;
   for (int s = 1; s <= 4; ++s) {
     if (N % (32 * s)) continue;
-    const size_t need = (size_t)(N / s) * (Cp + 8) * 2 + (size_t)FW * CSTEP * T * 32;
+    const size_t tab = (size_t)CSTEP * T * 32;
+    const size_t need = (size_t)(N / s) * (Cp + 8) * 2 +
+                        STREAM_PROD_WAVES * (tab > STAGE_BYTES ? tab : (size_t)STAGE_BYTES) +
+                        (FW - STREAM_PROD_WAVES) * tab;
     if (need <= (size_t)SMEM_BYTES) return s;
   }
   return 0;
@@ -700,8 +698,7 @@ int stream_forward(const void *xh, const float *offset, const float *mask, const
   a.pipi = (HW + PITEM - 1) / PITEM;
   a.cipi = (HW + CITEM - 1) / CITEM;
   a.nbands = (HW + BANDPX - 1) / BANDPX;
-  a.lag_px = env_int("GANET_STREAM_LAG_PX", 2048);
-  a.prod_waves = env_int("GANET_STREAM_PROD_WAVES", FW / 2);
+  a.prod_waves = STREAM_PROD_WAVES;
   a.whole_image = env_int("GANET_STREAM_WHOLE_IMAGE", 0);
   a.debug = env_int("GANET_STREAM_DEBUG_BITS", 0);
   // one workgroup per CU
