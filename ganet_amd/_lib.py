@@ -27,7 +27,7 @@ EXPORTS = (
     "ganet_deform_conv_workspace_bytes", "ganet_deform_conv_forward",
     "ganet_deform_conv_packed_weight_bytes", "ganet_deform_conv_pack_weight",
     "ganet_decode_workspace_bytes", "ganet_decode_batch", "ganet_group_batch",
-    "ganet_decode_pack", "ganet_deform_conv_algorithm",
+    "ganet_decode_pack", "ganet_deform_conv_algorithm", "ganet_deform_conv_status_offset",
     "ganet_deform_conv_backward_workspace_bytes", "ganet_deform_conv_backward",
     "ganet_decode_batch_noalloc",
 )
@@ -83,6 +83,8 @@ def lib():
         L.ganet_dcn_out_size.argtypes = [ctypes.c_int] * 5
         L.ganet_deform_conv_workspace_bytes.restype = ctypes.c_size_t
         L.ganet_deform_conv_workspace_bytes.argtypes = [ctypes.POINTER(DcnParams)]
+        L.ganet_deform_conv_status_offset.restype = ctypes.c_size_t
+        L.ganet_deform_conv_status_offset.argtypes = [ctypes.POINTER(DcnParams)]
         L.ganet_deform_conv_algorithm.restype = ctypes.c_int
         L.ganet_deform_conv_algorithm.argtypes = [ctypes.POINTER(DcnParams)]
         L.ganet_deform_conv_forward.restype = ctypes.c_int

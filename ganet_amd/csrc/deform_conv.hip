@@ -752,6 +752,12 @@ extern "C" int ganet_deform_conv_algorithm(const ganet_dcn_params *p) {
   return pl.stream ? 3 : (pl.cts ? 2 : 1);
 }
 
+extern "C" size_t ganet_deform_conv_status_offset(const ganet_dcn_params *p) {
+  Plan pl;
+  if (!p || make_plan(p, &pl) != GANET_OK || !pl.stream) return (size_t)-1;
+  return pl.xh_bytes;   // the control block's first word (CTL_ERROR) leads algorithm 3's scratch
+}
+
 extern "C" size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p) {
   Plan pl;
   if (make_plan(p, &pl) != GANET_OK) return 0;

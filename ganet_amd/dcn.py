@@ -78,9 +78,11 @@ def _packed_weight(L, weight, p):
 def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
                         dilation=(1, 1), groups=1, deformable_groups=1,
                         mask=None, bias=None, fuse_relu=False,
-                        offset_is_points=False, mfma_bf16=None, algo=0):
+                        offset_is_points=False, mfma_bf16=None, algo=0, check=False):
     """Raw forward on the HIP library.  `input` NCHW (contiguous or
-    channels_last) on a GPU; returns a tensor of the same memory format."""
+    channels_last) on a GPU; returns a tensor of the same memory format.
+    check=True synchronises and raises if the algorithm left a failure word in its
+    workspace (algorithm 3 only: ganet_deform_conv_status_offset)."""
     if not input.is_cuda:
         raise NotImplementedError
     if input.dtype not in _DTYPES:
@@ -164,6 +166,13 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
     if rc == _lib.GANET_ERR_BAD_SHAPE and mask is None and (H < kH or W < kW):
         raise RuntimeError("input image is smaller than kernel")
     _lib.check(rc, "ganet_deform_conv_forward")
+    if check:
+        off = L.ganet_deform_conv_status_offset(ctypes.byref(p))
+        if off != ctypes.c_size_t(-1).value:
+            word = int(ws[off:off + 4].view(torch.int32).item())   # synchronises
+            if word != 0:
+                raise RuntimeError("ganet_deform_conv_forward: algorithm 3 gave up waiting "
+                                   "(status word %d); the output is invalid" % word)
     return out
 
 

@@ -101,7 +101,11 @@ typedef struct {
                                (one fused gather+blend+MFMA kernel);
                                2 = contract-then-sample (per-tap GEMM into a
                                cache-resident scratch, then sampling; needs one
-                               deformable group, stride 1, 2*Cout <= Cin) */
+                               deformable group, stride 1, 2*Cout <= Cin);
+                               3 = algorithm 2 as ONE persistent launch (16-bit
+                               arithmetic, Cout <= 64 per tap, "same" output
+                               size; opt-in, never chosen automatically:
+                               slower than 2 on MI355X so far) */
   int32_t debug;            /* must be 0 (ablation bits of profiling builds) */
 } ganet_dcn_params;
 
@@ -115,10 +119,18 @@ int ganet_dcn_out_size(int in, int pad, int dilation, int k, int stride);
  * Returns 0 for invalid parameters. */
 size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p);
 
-/* Which algorithm ganet_deform_conv_forward runs for `p`: 1 or 2 as in
+/* Which algorithm ganet_deform_conv_forward runs for `p`: 1, 2 or 3 as in
  * ganet_dcn_params.algo (0 for invalid parameters).  No counterpart in the
  * reference; for logs and benchmarks. */
 int ganet_deform_conv_algorithm(const ganet_dcn_params *p);
+
+/* Algorithm 3 synchronises its workgroups through counters in the workspace; every wait
+ * is bounded, and a wait that runs out (a launch the GPU could not keep resident) leaves
+ * a non-zero 32-bit word in the workspace instead of hanging: the output is then invalid.
+ * Returns that word's byte offset inside `workspace` for `p`, or (size_t)-1 when the
+ * algorithm chosen for `p` has no such word.  The word is valid once the stream has
+ * finished the call.  No counterpart in the reference (its launches cannot fail this way). */
+size_t ganet_deform_conv_status_offset(const ganet_dcn_params *p);
 
 /* Weight pre-packing (no counterpart in the reference, which hands the raw
  * [Cout,Cin,kH,kW] tensor to cuBLAS on every call, deform_conv_cuda.cpp:228-236):
