@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W [--workload c3] [--dtype bf16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Without a launcher (WORLD_SIZE unset) and --gpus N > 1 this process starts N rank processes
+itself, one per GPU, as the reference's tools/dist_test.sh:13-24 does with
+torch.distributed.launch; it never touches the GPU, forwards rank 0's JSON line and exits
+with the worst rank's code.
+
 One "step" = one pass of the hot path over one batch of synthetic input that is
 already resident in HBM: the LFA (relu(DeformConv1D(x, pts - base)), one C-ABI call)
 followed by decode + lane grouping of the same batch and the async D2H copy of
@@ -170,6 +175,30 @@ def lfa_backward_side_measurement(dev, Cin, H, W, K, B=32, steps=20):
         return {"error": repr(exc)}
 
 
+def spawn_ranks(n, argv):
+    """One child process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in its environment),
+    started from a parent that has not initialised the GPU; nothing re-execs.  Rank 0's
+    stdout is this process's stdout.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    for pr in procs:
+        rc = pr.wait()
+        if rc != 0 and worst == 0:
+            worst = rc if rc > 0 else 1
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,10 +236,19 @@ def main():
                     help="copy the lane lists D2H on a second stream")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("GANET_BENCH_SPAWN_ONLY"):
+        # test hook (tests/test_bench_spawn.py): show what a rank was started with, touch no GPU
+        print(json.dumps({k: os.environ.get(k) for k in
+                          ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}),
+              flush=True)
+        return
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
