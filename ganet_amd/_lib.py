@@ -16,6 +16,7 @@ GANET_ERR_UNSUPPORTED = -3
 GANET_ERR_WORKSPACE = -4
 GANET_ERR_HIP = -5
 GANET_ERR_TOO_SMALL = -6
+GANET_ERR_NOT_FINITE = -7
 
 GANET_F32, GANET_BF16, GANET_F16 = 0, 1, 2
 GANET_NCHW, GANET_NHWC = 0, 1
@@ -30,7 +31,15 @@ EXPORTS = (
     "ganet_decode_pack", "ganet_deform_conv_algorithm", "ganet_deform_conv_status_offset",
     "ganet_deform_conv_backward_workspace_bytes", "ganet_deform_conv_backward",
     "ganet_decode_batch_noalloc",
+    "ganet_lanes_from_packed", "ganet_tusimple_from_lanes", "ganet_culane_text",
 )
+
+
+class LaneFormat(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "B", "by_center", "downscale", "points_thr", "float32_scalars", "threads",
+        "img_h", "img_w")] + [(n, ctypes.c_double) for n in (
+            "crop_x0", "crop_y0", "crop_x1", "crop_y1")]
 
 
 class DcnParams(ctypes.Structure):
@@ -121,6 +130,18 @@ def lib():
         L.ganet_decode_pack.argtypes = [ctypes.POINTER(DecodeParams),
                                        ctypes.POINTER(DecodeOut), ctypes.c_void_p,
                                        ctypes.c_size_t, ctypes.c_void_p]
+        L.ganet_lanes_from_packed.restype = ctypes.c_int
+        L.ganet_lanes_from_packed.argtypes = [
+            ctypes.c_void_p, ctypes.POINTER(LaneFormat), ctypes.c_void_p, ctypes.c_size_t,
+            ctypes.POINTER(ctypes.c_size_t)]
+        L.ganet_tusimple_from_lanes.restype = ctypes.c_int
+        L.ganet_tusimple_from_lanes.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+            ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.ganet_culane_text.restype = ctypes.c_int
+        L.ganet_culane_text.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+            ctypes.c_void_p]
         if L.ganet_abi_version() != 1:
             raise RuntimeError("ganet_amd: ABI version mismatch")
         _lib = L

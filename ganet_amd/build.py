@@ -18,9 +18,9 @@ COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
           "-Wall", "-Wno-unused-function"]
 # decode.hip must round like numpy / CPython: no fused multiply-add contraction.
-PER_FILE = {"decode.hip": ["-ffp-contract=off"]}
+PER_FILE = {"decode.hip": ["-ffp-contract=off"], "lane_format.hip": ["-ffp-contract=off"]}
 SOURCES = ["api.hip", "decode.hip", "deform_conv.hip", "deform_conv_cts.hip", "deform_conv_stream.hip",
-           "deform_conv_bwd.hip"]
+           "deform_conv_bwd.hip", "lane_format.hip"]
 
 
 def _newer(a, b):

@@ -10,6 +10,7 @@ extern "C" const char *ganet_status_string(int status) {
     case GANET_ERR_WORKSPACE: return "workspace missing or too small";
     case GANET_ERR_HIP: return "HIP runtime / kernel launch error";
     case GANET_ERR_TOO_SMALL: return "convolution input is too small";
+    case GANET_ERR_NOT_FINITE: return "a coordinate is not a finite 32-bit integer";
     default: return "unknown status";
   }
 }

@@ -102,6 +102,12 @@ class DecodeResult(object):
     def n_kpts(self, b=0):
         return int(self.header[b, 0])
 
+    def packed(self):
+        """header + records as one int32 stream (the layout of ganet_decode_pack), the input
+        of formats.format_batch."""
+        return np.concatenate([np.asarray(self.header, np.int32).reshape(-1),
+                               np.asarray(self.records, np.int32).reshape(-1)])
+
     def image(self, b=0):
         h = self.header[b]
         if h[3] & 7:

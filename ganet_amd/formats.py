@@ -17,12 +17,21 @@ The arithmetic is written on the same numpy / Python scalar types the reference
 handles, so numpy's promotion rules of the installed version apply identically
 (np.float32 * float is float64 before NEP 50 and float32 after it).
 
-`image_lanes` is the array form for the batched path: decoded image in, final integer
-lanes out, equal to PostProcessor -> adjust_result by construction and by test.
+`image_lanes` is the array form of one image: decoded image in, final integer lanes out,
+equal to PostProcessor -> adjust_result by construction and by test.
+
+`format_batch` is the production path: a whole decoded batch (the record stream of
+ganet_decode_pack) through the library's host routines ganet_lanes_from_packed /
+ganet_tusimple_from_lanes / ganet_culane_text - no per-point interpreter work; the Python
+structures of the reference are only built for the images a caller asks for.
 """
+import ctypes
 import json
+import os
 
 import numpy as np
+
+from . import _lib
 
 
 def adjust_result(lanes, centers, crop_bbox, img_shape, points_thr):
@@ -147,3 +156,127 @@ def out_result(lanes, dst=None):
     if dst is not None:
         with open(dst, 'w') as f:
             f.write(culane_lines_text(lanes))
+
+
+def float32_scalars():
+    """1 if this NumPy keeps `np.float32 * python_float` in float32 (NumPy >= 2), else 0."""
+    return int(_scalar_dtype(np.float32(1), 0.5) == np.float32)
+
+
+def packed_from_images(images, by_center=True):
+    """The record stream of ganet_decode_pack (include/ganet_hip.h) built on the host from
+    per-image arrays (dicts as DecodeResult.image() returns them: kpt_gid, n_groups, align,
+    root, group_center; kpt_xy / centers / center_gid / group_count optional).  For callers
+    that hold decoded images as arrays (tests, CPU pipelines)."""
+    B = len(images)
+    header = np.zeros((B, 8), np.int32)
+    recs, off = [], 0
+    for b, im in enumerate(images):
+        gid = np.asarray(im["kpt_gid"], np.int32).reshape(-1)
+        nk, ng = len(gid), int(im["n_groups"])
+        cen = np.asarray(im.get("centers", np.zeros((0, 2))), np.int32).reshape(-1, 2)
+        nc = len(cen)
+        gc = np.asarray(im["group_center"], np.int32).reshape(-1, 2) if by_center \
+            else np.zeros((0, 2), np.int32)
+        assert len(gc) == (ng if by_center else 0)
+        parts = [np.asarray(im.get("kpt_xy", np.zeros((nk, 2))), np.int32).reshape(-1),
+                 np.ascontiguousarray(im["align"], np.float32).reshape(-1).view(np.int32),
+                 np.ascontiguousarray(im["root"], np.float32).reshape(-1).view(np.int32),
+                 gid, cen.reshape(-1),
+                 np.asarray(im.get("center_gid", np.zeros(nc)), np.int32).reshape(-1),
+                 gc.reshape(-1),
+                 np.asarray(im.get("group_count", np.zeros(ng)), np.int32).reshape(-1)]
+        rec = np.concatenate(parts).astype(np.int32)
+        header[b, :6] = (nk, nc, ng, 0, off, len(rec))
+        recs.append(rec)
+        off += len(rec)
+    header[0, 6] = off
+    return np.concatenate([header.reshape(-1)] + recs).astype(np.int32)
+
+
+class BatchLanes(object):
+    """Final integer lanes of a batch (ganet_lanes_from_packed).  image(b) rebuilds the
+    reference's Python structures for one image; tusimple() / culane_texts() give the wire
+    formats for the whole batch."""
+
+    def __init__(self, stream, B, threads):
+        self.stream, self.B, self.threads = stream, B, threads
+        self.header = stream[:4 * B].reshape(B, 4)
+
+    def n_lanes(self):
+        return self.header[:, 0]
+
+    def image(self, b):
+        nl, ncc, off, words = (int(v) for v in self.header[b])
+        rec = self.stream[4 * self.B + off:4 * self.B + off + words]
+        results, vcs, pos = [], [], 0
+        for _ in range(nl):
+            n = int(rec[pos + 1])
+            pts = rec[pos + 2:pos + 2 + 2 * n].reshape(n, 2).tolist()
+            cts = rec[pos + 2 + 2 * n:pos + 2 + 4 * n].reshape(n, 2).tolist()
+            results.append([tuple(p) for p in pts])
+            vcs.append([tuple(c) for c in cts])
+            pos += 2 + 4 * n
+        ccs = [tuple(c) for c in rec[pos:pos + 2 * ncc].reshape(ncc, 2).tolist()]
+        return results, vcs, ccs
+
+    def tusimple(self, h_samples, reg_x=-2):
+        """tusimple_convert_formal for every image: (xs [total lanes, len(h_samples)] int32,
+        lane_start [B+1])."""
+        L = _lib.lib()
+        hs = np.ascontiguousarray(h_samples, np.int32)
+        start = np.zeros(self.B + 1, np.int32)
+        xs = np.empty((int(self.header[:, 0].sum()), len(hs)), np.int32)
+        rc = L.ganet_tusimple_from_lanes(self.stream.ctypes.data, self.B, hs.ctypes.data, len(hs),
+                                         reg_x, self.threads, xs.ctypes.data, xs.size,
+                                         start.ctypes.data)
+        _lib.check(rc, "ganet_tusimple_from_lanes")
+        return xs, start
+
+    def tusimple_json_lines(self, h_samples, raw_files, run_time=20):
+        """One submission line per image (tusimple/test_dataset.py:203-213)."""
+        xs, start = self.tusimple(h_samples)
+        hs = [int(h) for h in h_samples]
+        return [json.dumps(dict(lanes=xs[start[b]:start[b + 1]].tolist(), h_samples=hs,
+                                raw_file=raw_files[b], run_time=run_time))
+                for b in range(self.B)]
+
+    def culane_texts(self):
+        """The `.lines.txt` text of every image (culane/test_dataset.py:138-148)."""
+        L = _lib.lib()
+        start = np.zeros(2 * self.B + 1, np.uint64)
+        L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads, None, 0,
+                            start.ctypes.data)
+        buf = np.empty(max(int(start[self.B]), 1), np.uint8)
+        rc = L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads, buf.ctypes.data,
+                                 buf.size, start.ctypes.data)
+        _lib.check(rc, "ganet_culane_text")
+        raw = buf.tobytes()
+        return [raw[int(start[b]):int(start[b]) + int(start[self.B + 1 + b])].decode("ascii")
+                for b in range(self.B)]
+
+
+def format_batch(packed, B, by_center, downscale, crop_bbox, img_shape, points_thr, threads=0):
+    """lane_post_process + adjust_result for a whole batch.  `packed`: the int32 record stream
+    of ganet_decode_pack on the host (DecodeResult.packed(), HotPath's pinned block, or
+    packed_from_images).  Raises ValueError where the reference's int() would
+    (NaN / infinite coordinates)."""
+    L = _lib.lib()
+    packed = np.ascontiguousarray(packed, np.int32)
+    f = _lib.LaneFormat()
+    f.B, f.by_center, f.downscale, f.points_thr = B, int(bool(by_center)), int(downscale), int(points_thr)
+    f.float32_scalars = float32_scalars()
+    f.threads = threads or min(16, len(os.sched_getaffinity(0)))
+    f.img_h, f.img_w = int(img_shape[0]), int(img_shape[1])
+    f.crop_x0, f.crop_y0, f.crop_x1, f.crop_y1 = (float(v) for v in crop_bbox)
+    need = ctypes.c_size_t(0)
+    rc = L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), None, 0, ctypes.byref(need))
+    if rc not in (_lib.GANET_OK, _lib.GANET_ERR_WORKSPACE):
+        _lib.check(rc, "ganet_lanes_from_packed")
+    out = np.empty(need.value, np.int32)
+    rc = L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), out.ctypes.data, out.size,
+                                   ctypes.byref(need))
+    if rc == _lib.GANET_ERR_NOT_FINITE:
+        raise ValueError("cannot convert a non-finite coordinate to integer")
+    _lib.check(rc, "ganet_lanes_from_packed")
+    return BatchLanes(out, B, f.threads)

@@ -37,7 +37,9 @@ typedef enum {
   GANET_ERR_UNSUPPORTED = -3, /* valid for the reference, not built here yet */
   GANET_ERR_WORKSPACE = -4,   /* workspace_bytes smaller than the query says */
   GANET_ERR_HIP = -5,         /* a HIP call / kernel launch failed */
-  GANET_ERR_TOO_SMALL = -6    /* convolution output would be empty */
+  GANET_ERR_TOO_SMALL = -6,   /* convolution output would be empty */
+  GANET_ERR_NOT_FINITE = -7   /* a coordinate Python's int() would refuse (NaN, infinity)
+                                 or that no int32 holds (host formatting calls) */
 } ganet_status;
 
 typedef enum { GANET_F32 = 0, GANET_BF16 = 1, GANET_F16 = 2 } ganet_dtype;
@@ -304,6 +306,60 @@ int ganet_group_batch(const ganet_decode_params *p, const ganet_decode_out *out,
  * Records are laid out in image order.  packed_words >= 8*B. */
 int ganet_decode_pack(const ganet_decode_params *p, const ganet_decode_out *out,
                       int32_t *packed, size_t packed_words, ganet_stream_t stream);
+
+/* ---- after grouping: records -> the reference's result formats (host code) -----------
+ * The reference runs these per image in Python (one interpreter step per point); here one
+ * call formats a whole batch from the record stream of ganet_decode_pack on `threads` host
+ * threads.  Nothing here touches the GPU; `packed` is host memory.
+ *
+ * ganet_lanes_from_packed =
+ *   PostProcessor.lane_post_process   tools/ganet/post_process.py:216-242
+ *     (groups of more than one point become lanes, points = align * downscale as float32,
+ *      centers = root * downscale as float64, cluster centres = group_center * downscale)
+ *   adjust_result   tools/ganet/tusimple/test_dataset.py:49-83 == culane/test_dataset.py:79-113
+ *     (`int(v * ratio + offset)`, ratio = crop extent / network input extent, truncation
+ *      towards zero; lanes with more than points_thr points are kept).
+ * float32_scalars: how NumPy evaluates `np.float32 * python_float` for the points - 1 keeps
+ * float32 (NumPy >= 2), 0 promotes to float64 (NumPy 1.x, the reference's own environment).
+ * Layout of `lanes` (int32):
+ *   header[B][4]: lanes kept, cluster centres, record offset in words counted from the end
+ *                 of the header, record words
+ *   record b    : per lane { id_class, n, points[2n] (x, y), centers[2n] } in group order,
+ *                 then cluster_centers[2 * centres]
+ * *needed_words is always set; GANET_ERR_WORKSPACE when lanes_words is smaller (lanes may be
+ * NULL to query).  GANET_ERR_BAD_SHAPE for a record with capacity overflow bits set,
+ * GANET_ERR_NOT_FINITE where Python's int() raises. */
+typedef struct ganet_lane_format {
+  int32_t B;
+  int32_t by_center;        /* records carry group centres (cluster_by_center_thr given) */
+  int32_t downscale;        /* hm_down_scale (8 or 4) */
+  int32_t points_thr;
+  int32_t float32_scalars;
+  int32_t threads;          /* host threads over images (<= 1: the calling thread) */
+  int32_t img_h, img_w;     /* img_shape[:2], the network input */
+  double crop_x0, crop_y0, crop_x1, crop_y1;   /* crop_bbox in original-image pixels */
+} ganet_lane_format;
+
+int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_format *f, int32_t *lanes,
+                            size_t lanes_words, size_t *needed_words);
+
+/* tusimple_convert_formal / get_line_intersection (tools/ganet/common.py:118-147) on the
+ * stream of ganet_lanes_from_packed: x of every kept lane at each of the n_h rows of
+ * h_samples (first segment whose y range holds the row, `int(k*(y-y0)+x0+0.49999)`),
+ * reg_x (-2) where the lane has none.  lane_start[B+1]: first row of xs of every image;
+ * xs[lane_start[B]][n_h].  GANET_ERR_WORKSPACE when xs_words is too small (lane_start is
+ * filled all the same). */
+int ganet_tusimple_from_lanes(const int32_t *lanes, int B, const int32_t *h_samples, int n_h,
+                              int reg_x, int threads, int32_t *xs, size_t xs_words,
+                              int32_t *lane_start);
+
+/* out_result (tools/ganet/culane/test_dataset.py:138-148): the text of every image's
+ * `.lines.txt` - one lane per line, "x y" pairs printed with two decimals.
+ * text_start[2B+1]: [0..B] start of every image's slot in `text` (slot sizes are upper
+ * bounds; text_start[B] = bytes needed), [B+1..2B] bytes used in every slot.
+ * GANET_ERR_WORKSPACE when text_bytes < text_start[B] (text may be NULL to query). */
+int ganet_culane_text(const int32_t *lanes, int B, int threads, char *text, size_t text_bytes,
+                      size_t *text_start);
 
 #ifdef __cplusplus
 }

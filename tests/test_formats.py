@@ -120,3 +120,105 @@ def test_gpu_decode_to_result_files(name):
     result, vcs, ccs = formats.adjust_result(lanes, centers, tuple(c["crop_bbox"]),
                                              tuple(c["img_shape"]), c["points_thr"])
     check_against_golden(c, result, vcs, ccs)
+
+
+# ---- whole batches through the library's host routines (ganet_lanes_from_packed & co) ----
+
+def _batch_from_golden(names):
+    imgs = [oracle_image(G.load_decode_case(n)) for n in names]
+    return imgs
+
+
+@pytest.mark.parametrize("dataset", ["tusimple", "culane"])
+def test_format_batch_matches_reference_golden(dataset):
+    """Every golden case of one dataset as ONE batch: the C++ routines give the reference's
+    adjust_result / tusimple_convert_formal / out_result answers image by image."""
+    names = [n for n in sorted(CASES) if CASES[n]["dataset"] == dataset]
+    groups = {}
+    for n in names:      # one call per (downscale, crop, shape, thr, grouping mode) setting
+        c, d = CASES[n], G.load_decode_case(n)
+        key = (c["downscale"], tuple(c["crop_bbox"]), tuple(c["img_shape"]), c["points_thr"],
+               d["by_center_thr"] is not None)
+        groups.setdefault(key, []).append(n)
+    assert groups
+    for (ds, crop, shape, thr, by_center), members in groups.items():
+        imgs = _batch_from_golden(members)
+        packed = formats.packed_from_images(imgs, by_center=by_center)
+        for threads in (1, 3):
+            bl = formats.format_batch(packed, len(imgs), by_center, ds, crop, shape, thr,
+                                      threads=threads)
+            texts = bl.culane_texts()
+            for b, n in enumerate(members):
+                c = CASES[n]
+                r, v, cc = bl.image(b)
+                check_against_golden(c, r, v, cc)
+                if dataset == "culane":
+                    assert texts[b] == c["lines_txt"]
+                else:
+                    xs, start = bl.tusimple(c["h_samples"])
+                    assert xs[start[b]:start[b + 1]].tolist() == c["tusimple_lanes"]
+                    line = json.loads(bl.tusimple_json_lines(c["h_samples"],
+                                                             ["a/b.jpg"] * len(members))[b])
+                    assert line["lanes"] == c["tusimple_lanes"]
+
+
+def test_format_batch_equals_python_mirror_on_random_images():
+    """Random grouped images (negative and large coordinates, empty images, dropped
+    keypoints, groups at the points_thr boundary): batch routine == image_lanes."""
+    rng = np.random.default_rng(0)
+    imgs = []
+    for b in range(37):
+        nk = int(rng.integers(0, 60)) if b % 5 else 0
+        ng = int(rng.integers(0, 7)) if nk else 0
+        gid = rng.integers(-1, max(ng, 1), nk).astype(np.int32) if ng else -np.ones(nk, np.int32)
+        imgs.append(dict(kpt_gid=gid, n_groups=ng,
+                         align=(rng.standard_normal((nk, 2)) * 300).astype(np.float32),
+                         root=(rng.standard_normal((nk, 2)) * 300).astype(np.float32),
+                         group_center=rng.integers(-50, 400, (ng, 2)).astype(np.int32)))
+    crop, shape = (0, 270, 1640, 590), (320, 800, 3)
+    for thr in (0, 3):
+        bl = formats.format_batch(formats.packed_from_images(imgs), len(imgs), True, 8, crop,
+                                  shape, thr, threads=4)
+        for b, im in enumerate(imgs):
+            assert bl.image(b) == formats.image_lanes(im, 8, crop, shape, thr)
+        txt = bl.culane_texts()
+        for b, im in enumerate(imgs):
+            assert txt[b] == formats.culane_lines_text(formats.image_lanes(im, 8, crop, shape, thr)[0])
+
+
+def test_format_batch_rejects_non_finite_like_int():
+    img = dict(kpt_gid=np.array([0, 0], np.int32), n_groups=1,
+               align=np.array([[1, 2], [np.nan, 3]], np.float32),
+               root=np.zeros((2, 2), np.float32), group_center=np.zeros((1, 2), np.int32))
+    with pytest.raises(ValueError):
+        formats.format_batch(formats.packed_from_images([img]), 1, True, 8,
+                             (0, 160, 1280, 720), (320, 800, 3), 0)
+
+
+def test_lanes_from_packed_legacy_float64_scalars():
+    """float32_scalars = 0: NumPy 1.x (the reference's own environment) promotes
+    `np.float32 * python_float` to float64; checked against that formula written out."""
+    import ctypes
+    from ganet_amd import _lib
+    rng = np.random.default_rng(3)
+    nk = 40
+    img = dict(kpt_gid=np.zeros(nk, np.int32), n_groups=1,
+               align=(rng.standard_normal((nk, 2)) * 77).astype(np.float32),
+               root=(rng.standard_normal((nk, 2)) * 77).astype(np.float32),
+               group_center=np.array([[5, 9]], np.int32))
+    packed = formats.packed_from_images([img])
+    f = _lib.LaneFormat()
+    f.B, f.by_center, f.downscale, f.points_thr, f.float32_scalars, f.threads = 1, 1, 8, 0, 0, 1
+    f.img_h, f.img_w = 320, 800
+    f.crop_x0, f.crop_y0, f.crop_x1, f.crop_y1 = 0.0, 270.0, 1640.0, 590.0
+    need = ctypes.c_size_t(0)
+    L = _lib.lib()
+    L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), None, 0, ctypes.byref(need))
+    out = np.empty(need.value, np.int32)
+    assert L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), out.ctypes.data,
+                                     out.size, ctypes.byref(need)) == 0
+    pts = out[4 + 2:4 + 2 + 2 * nk].reshape(nk, 2)
+    rx, ry = 1640 / 800, (590 - 270) / 320
+    a = (img["align"] * np.float32(8)).astype(np.float64)
+    exp = np.stack([np.trunc(a[:, 0] * rx + 0), np.trunc(a[:, 1] * ry + 270)], 1).astype(np.int64)
+    assert np.array_equal(pts, exp)
