@@ -135,7 +135,27 @@ def cpu_baseline_and_parity(wl, dtype, d, hp, n_images, threads):
                        and np.array_equal(img["group_center"], means))
         parity["decode_bit_exact"] = ok
     total = t_lfa + t_dec
+    # the same port on ONE thread, on the first images of the sample
+    n1 = min(n, 8)
+    t0 = time.perf_counter()
+    O.deform_conv_forward(x_host[:n1], off_host[:n1], w_host, (1, 1), (0, (K - 1) // 2), (1, 1),
+                          acc64=False, nthreads=1)
+    if wl["decode"]:
+        O.decode_group_batch(d["heat_host"][:n1], d["off_host"][:n1], d["err_host"][:n1],
+                             cfg["thr"], cfg["root_thr"], float(cfg["T"]), float(cfg["T"]),
+                             nthreads=1)
+    t_single = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return dict(value=n / total, unit="images/s", cores=threads, kind="port",
+                single_thread=dict(value=n1 / t_single, unit="images/s", images=n1),
+                nproc=os.cpu_count(), cpu_share=len(os.sched_getaffinity(0)), cpu_model=model,
                 sample="%d of the %d images of the timed batch (same seeded inputs): "
                        "oracle LFA fp32 %.2fs + decode/grouping %.3fs, OpenMP over images"
                        % (n, wl["B"], t_lfa, t_dec),
@@ -232,6 +252,12 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="LFA and decode on one stream (default: decode/grouping/pack run on "
                          "a stream of their own beside the LFA - they do not depend on it)")
+    ap.add_argument("--consume", action="store_true",
+                    help="inside the timed region, turn every step's records into the final "
+                         "result format on the host (lane_post_process + adjust_result + "
+                         "CULane .lines.txt text, C++ behind the C-ABI), one step behind the GPU")
+    ap.add_argument("--format-threads", type=int, default=0,
+                    help="host threads of the formatting routines (0: CPU share, at most 16)")
     ap.add_argument("--overlap-copy", action="store_true",
                     help="copy the lane lists D2H on a second stream")
     args = ap.parse_args()
@@ -297,6 +323,7 @@ def main():
         if hp.side is not None:
             # two streams: the LFA on the current one, decode beside it (HotPath.step)
             cur = torch.cuda.current_stream(dev)
+            hp.side_wait()
             hp.inputs_ready.record(cur)
             if ev is not None:
                 ev[0].record()
@@ -308,6 +335,7 @@ def main():
                 if ev is not None:
                     ev[3].record()
                 hp.decode(d["heat"], d["off"], d["err"])
+                hp.side_mark()
                 if ev is not None:
                     ev[2].record()
             return
@@ -351,17 +379,47 @@ def main():
         if over:
             raise SystemExit("decode capacity overflow in the bench configuration")
 
+    # records -> final result format on the host: what the reference does per
+    # image in Python after grouping (post_process.py:216-242, culane/test_dataset.py:79-148)
+    fmt_threads = args.format_threads or min(16, len(os.sched_getaffinity(0)))
+    fmt_crop, fmt_shape, fmt_thr = (0, 270, 1640, 590), (8 * H if cfg["ds"] == 8 else 4 * H,
+                                                         8 * W if cfg["ds"] == 8 else 4 * W), 4
+
+    def consume(slot):
+        from ganet_amd import formats
+        bl = formats.format_batch(hp.packed(slot), B, True, cfg["ds"], fmt_crop, fmt_shape,
+                                  fmt_thr, threads=fmt_threads)
+        texts = bl.culane_texts()
+        return int(bl.n_lanes().sum()), sum(len(t) for t in texts)
+
+    if args.consume and (graph is not None or not wl["decode"]):
+        raise SystemExit("--consume needs the eager flow of a workload with decode")
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)]
               for _ in range(args.steps)]
+    consumed = [0, 0]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    prev_slot = None
     for i in range(args.steps):
         if graph is not None:
             graph.replay()
         else:
             one_step(events[i])
+        if args.consume:
+            # step i is enqueued; format step i-1 (its result block is not reused before
+            # step i+1 is enqueued)
+            slot = hp.last
+            if prev_slot is not None:
+                nl, nb = consume(prev_slot)
+                consumed[0] += nl
+                consumed[1] += nb
+            prev_slot = slot
+    if args.consume and prev_slot is not None:
+        nl, nb = consume(prev_slot)
+        consumed[0] += nl
+        consumed[1] += nb
     torch.cuda.synchronize()          # all streams of the device, copies included
     if dist is not None:
         dist.barrier()
@@ -398,16 +456,30 @@ def main():
         lfa_s = lfa_ms * 1e-3
         hbm_achieved = nbytes / lfa_s / 1e9
         mfma_achieved = flops / lfa_s / 1e12
-        traffic = None
+        # measured L2<->fabric bytes per LFA call: written by tools/traffic_json.py from the
+        # PMC passes of tools/profile.sh; only quoted while the kernel sources are the ones
+        # that were profiled
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
                 key = "%s_%s" % (args.workload, dtype)
                 if dtype == "fp32" and args.fp32_mode != "auto":
                     key += "_" + args.fp32_mode
-                traffic = json.load(open(tfile)).get(key)
-            except Exception:
-                traffic = None
+                if args.algo:
+                    key += "_algo%d" % args.algo
+                ent = json.load(open(tfile)).get(key)
+                if isinstance(ent, dict):
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    from traffic_json import kernel_source_hash
+                    if ent.get("kernel_sources") == kernel_source_hash():
+                        traffic = ent["bytes"]
+                        traffic_source = "%s @ %s" % (ent.get("summary"), ent.get("head", "")[:7])
+                    else:
+                        traffic_source = ("stale: %s was measured on other kernel sources (%s)"
+                                          % (ent.get("summary"), ent.get("head", "")[:7]))
+            except Exception as exc:  # noqa: BLE001
+                traffic, traffic_source = None, "unreadable: %r" % (exc,)
         if t_mfma >= t_hbm:
             roof = dict(bound="mfma", achieved=mfma_achieved,
                         peak=peak_tflops, unit="TFLOP/s",
@@ -420,7 +492,7 @@ def main():
                    % ("cts_gemm_split_kernel" if split else
                       "cts_gemm_ov_kernel" if dtype != "fp32" and Cin in (64, 128, 256)
                       and os.environ.get("GANET_CTS_GEMM", "o")[0] != "t" else "cts_gemm_kernel"))
-        roof.update(traffic=traffic, kernel=kernels, lfa_algorithm=hp.lfa_algorithm,
+        roof.update(traffic=traffic, traffic_source=traffic_source, kernel=kernels, lfa_algorithm=hp.lfa_algorithm,
                     kernel_ms=lfa_ms, algorithmic_bytes=nbytes, algorithmic_flops=flops,
                     hbm_gbs=hbm_achieved, hbm_frac=hbm_achieved / HBM_PEAK_GBS,
                     mfma_tflops=mfma_achieved,
@@ -449,6 +521,10 @@ def main():
                        "layout": "NHWC (channels_last) resident in HBM",
                        "fp32_mode": args.fp32_mode if dtype == "fp32" else None,
                        "launch": "hip graph replay" if graph is not None else "eager",
+                       "consume": ("every step's records formatted on the host inside the timed "
+                                   "region, one step behind the GPU") if args.consume else
+                                  "records land in pinned host memory; formatting timed beside "
+                                  "(host_format)",
                        "streams": ("LFA and decode on two streams" if hp.side is not None
                                    else "one stream"),
                        "parallelism": "image-sharded x%d, no collective" % world},
@@ -461,8 +537,33 @@ def main():
             dbytes = decode_algorithmic(B, H, W)
             out["decode_images_per_s_per_gpu"] = B / (dec_ms * 1e-3)
             out["decode_hbm_gbs"] = dbytes / (dec_ms * 1e-3) / 1e9
+        if wl["decode"] and graph is None:
+            # host formatting of the timed batch, outside the timed region unless --consume
+            slot = hp.last
+            consume(slot)
+            reps = 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                nl, nb = consume(slot)
+            t_fmt = (time.perf_counter() - t0) / reps
+            gpu_ips = B * args.steps / elapsed
+            out["host_format"] = {
+                "value": B / t_fmt, "unit": "images/s", "cores": fmt_threads,
+                "ms_per_batch": t_fmt * 1e3, "lanes_per_batch": nl, "text_bytes_per_batch": nb,
+                "what": "records -> lane_post_process + adjust_result (int lanes, more than "
+                        "%d points) + CULane .lines.txt text, ganet_lanes_from_packed + "
+                        "ganet_culane_text" % fmt_thr,
+                "inside_timed_region": bool(args.consume),
+                "end_to_end_bound": "gpu" if B / t_fmt >= gpu_ips else "host formatting",
+            }
+            if args.consume:
+                out["host_format"]["lanes_in_timed_region"] = consumed[0]
         if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            # every core this process may use: its affinity mask, or what the box grants
+            # through OMP_NUM_THREADS where that is smaller (nproc shows the whole machine)
+            avail = len(os.sched_getaffinity(0))
+            omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+            threads = args.cpu_threads or (min(avail, omp) if omp > 0 else avail)
             base, parity = cpu_baseline_and_parity(wl, dtype, d, hp, args.cpu_images,
                                                    threads)
             out["cpu_baseline"] = base

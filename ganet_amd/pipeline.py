@@ -79,7 +79,7 @@ class HotPath(object):
                 budget = min(budget, bufs.packed_words)
                 host = torch.empty(bufs.packed_words, dtype=torch.int32, pin_memory=True)
                 bufs.budget = budget
-                self.slots.append(dict(bufs=bufs, host=host,
+                self.slots.append(dict(bufs=bufs, host=host, ready=torch.cuda.Event(),
                                        done=torch.cuda.Event(), copied=torch.cuda.Event()))
             self.cur = 0
             self.last = None
@@ -94,6 +94,8 @@ class HotPath(object):
             # extending the step.
             self.side = torch.cuda.Stream(device=self.device) if side_decode else None
             self.inputs_ready = torch.cuda.Event() if side_decode else None
+            self.side_done = torch.cuda.Event() if side_decode else None
+            self._side_busy = False
             self.pack_to_host = pack_to_host and not overlap_copy
             self.copy_stream = (torch.cuda.Stream(device=self.device) if overlap_copy
                                 else None)
@@ -146,6 +148,7 @@ class HotPath(object):
                 slot["host"].data_ptr(), slot["host"].numel(), cur_stream.cuda_stream)
             _lib.check(rc, "ganet_decode_pack")
             slot["direct"] = True
+            slot["ready"].record(cur_stream)
             self.last = slot
             self.cur ^= 1
             return
@@ -161,21 +164,40 @@ class HotPath(object):
                     slot["copied"].record(self.copy_stream)
             else:
                 slot["host"][:n].copy_(slot["bufs"].packed[:n], non_blocking=True)
+        slot["ready"].record(self.copy_stream if (copy_to_host and self.overlap_copy)
+                             else cur_stream)
         self.last = slot
         self.cur ^= 1
 
     def step(self, x, pts, heat, offset, error):
+        """One pass of the hot path.  Lifetime contract with side_decode: decode, grouping and
+        pack read heat/offset/error on the side stream; the caller's stream is made to wait
+        for them at the start of the NEXT step (side_wait()), so those tensors must stay
+        alive and unchanged until then (or until result()); a caller that frees or rewrites
+        them earlier calls side_wait() itself first."""
         if self.side is None:
             self.lfa(x, pts)
             self.decode(heat, offset, error)
             return
         # the step's inputs are ready where the current stream stands now
         cur = torch.cuda.current_stream(self.device)
+        self.side_wait()
         self.inputs_ready.record(cur)
         self.lfa(x, pts)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.inputs_ready)
             self.decode(heat, offset, error)
+            self.side_mark()
+
+    def side_wait(self):
+        """The current stream waits for the side stream's last decode (no host wait)."""
+        if self.side is not None and self._side_busy:
+            torch.cuda.current_stream(self.device).wait_event(self.side_done)
+
+    def side_mark(self):
+        """Called on the side stream after a decode was enqueued there."""
+        self.side_done.record(torch.cuda.current_stream(self.device))
+        self._side_busy = True
 
     def capture(self, x, pts, heat, offset, error):
         """Record one step on these (fixed) input tensors into a HIP graph and return
@@ -199,18 +221,35 @@ class HotPath(object):
         self.cur = first ^ 1
         return graph
 
-    def result(self):
-        """Wait for the last step's copy and view its decode result."""
-        torch.cuda.current_stream(self.device).synchronize()
-        if self.copy_stream is not None:
-            self.copy_stream.synchronize()
-        if self.side is not None:
-            self.side.synchronize()
-        slot = self.last
+    def result(self, slot=None):
+        """Wait for a step's lane lists and view them.  slot=None: the last step, after
+        everything enqueued so far; a slot (HotPath.last, remembered by the caller right
+        after a step) is waited for alone, so the next step may already be running."""
+        if slot is None:
+            torch.cuda.current_stream(self.device).synchronize()
+            if self.copy_stream is not None:
+                self.copy_stream.synchronize()
+            if self.side is not None:
+                self.side.synchronize()
+            slot = self.last
+        else:
+            slot["ready"].synchronize()
+        host, total = self._host_stream(slot)
+        hw = slot["bufs"].header_words
+        header = host[:hw].reshape(self.B, _lib.DECODE_COUNT_STRIDE)
+        return DecodeResult(header.copy(), host[hw:total].copy(), self.params, grouped=True)
+
+    def _host_stream(self, slot):
         bufs, host = slot["bufs"], slot["host"].numpy()
         total = bufs.header_words + int(host[6])
         if not slot.get("direct") and total > bufs.budget:   # beyond the async budget
             slot["host"][bufs.budget:total].copy_(bufs.packed[bufs.budget:total])
-        header = host[:bufs.header_words].reshape(self.B, _lib.DECODE_COUNT_STRIDE)
-        return DecodeResult(header.copy(), host[bufs.header_words:total].copy(),
-                            self.params, grouped=True)
+        return host, total
+
+    def packed(self, slot):
+        """The record stream of a step (header + records, the layout of ganet_decode_pack)
+        as a view of the pinned host block - the input of formats.format_batch.  Waits for
+        that step only; valid until the step after next reuses the block."""
+        slot["ready"].synchronize()
+        host, total = self._host_stream(slot)
+        return host[:total]
