@@ -252,10 +252,15 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="LFA and decode on one stream (default: decode/grouping/pack run on "
                          "a stream of their own beside the LFA - they do not depend on it)")
-    ap.add_argument("--consume", action="store_true",
+    ap.add_argument("--no-consume", dest="consume", action="store_false",
+                    help="stop the timed region at the packed records in pinned host memory "
+                         "(default: consume them, as the reference's speed test includes "
+                         "PostProcessor, tools/ganet/speed_test.py:57-65)")
+    ap.add_argument("--consume", dest="consume", action="store_true", default=True,
                     help="inside the timed region, turn every step's records into the final "
                          "result format on the host (lane_post_process + adjust_result + "
-                         "CULane .lines.txt text, C++ behind the C-ABI), one step behind the GPU")
+                         "CULane .lines.txt text, C++ behind the C-ABI) on two host threads "
+                         "beside the enqueueing one")
     ap.add_argument("--format-threads", type=int, default=0,
                     help="host threads of the formatting routines (0: CPU share, at most 16)")
     ap.add_argument("--overlap-copy", action="store_true",
@@ -387,13 +392,13 @@ def main():
 
     def consume(slot):
         from ganet_amd import formats
-        bl = formats.format_batch(hp.packed(slot), B, True, cfg["ds"], fmt_crop, fmt_shape,
+        bl = formats.format_batch(hp.records(slot), B, True, cfg["ds"], fmt_crop, fmt_shape,
                                   fmt_thr, threads=fmt_threads)
-        texts = bl.culane_texts()
-        return int(bl.n_lanes().sum()), sum(len(t) for t in texts)
+        buf, start, length = bl.culane_text_buffer()
+        return int(bl.n_lanes().sum()), int(length.sum())
 
-    if args.consume and (graph is not None or not wl["decode"]):
-        raise SystemExit("--consume needs the eager flow of a workload with decode")
+    if graph is not None or not wl["decode"]:
+        args.consume = False     # nothing to format / no per-step result block under a graph
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)]
               for _ in range(args.steps)]
     consumed = [0, 0]
@@ -401,25 +406,30 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    prev_slot = None
+    # --consume: two host threads format finished steps while this one enqueues the next
+    # (the library calls release the GIL); a result block is reused every second step, so
+    # step i+2 is enqueued only after step i has been formatted
+    pool, pending = None, {}
+    if args.consume:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=2)
     for i in range(args.steps):
+        if pool is not None and hp.cur in pending:
+            nl, nb = pending.pop(hp.cur).result()
+            consumed[0] += nl
+            consumed[1] += nb
         if graph is not None:
             graph.replay()
         else:
             one_step(events[i])
-        if args.consume:
-            # step i is enqueued; format step i-1 (its result block is not reused before
-            # step i+1 is enqueued)
-            slot = hp.last
-            if prev_slot is not None:
-                nl, nb = consume(prev_slot)
-                consumed[0] += nl
-                consumed[1] += nb
-            prev_slot = slot
-    if args.consume and prev_slot is not None:
-        nl, nb = consume(prev_slot)
+        if pool is not None:
+            pending[hp.cur ^ 1] = pool.submit(consume, hp.last)
+    for fut in pending.values():
+        nl, nb = fut.result()
         consumed[0] += nl
         consumed[1] += nb
+    if pool is not None:
+        pool.shutdown()
     torch.cuda.synchronize()          # all streams of the device, copies included
     if dist is not None:
         dist.barrier()
@@ -522,7 +532,7 @@ def main():
                        "fp32_mode": args.fp32_mode if dtype == "fp32" else None,
                        "launch": "hip graph replay" if graph is not None else "eager",
                        "consume": ("every step's records formatted on the host inside the timed "
-                                   "region, one step behind the GPU") if args.consume else
+                                   "region, two host threads beside the GPU") if args.consume else
                                   "records land in pinned host memory; formatting timed beside "
                                   "(host_format)",
                        "streams": ("LFA and decode on two streams" if hp.side is not None

@@ -54,10 +54,8 @@ inline float as_f32(int32_t bits) {
 // Python's int(): truncation towards zero; NaN / infinity raise there, and so does a value
 // no int32 holds here
 inline bool to_int(double t, int32_t *out) {
-  if (!std::isfinite(t)) return false;
-  t = std::trunc(t);
-  if (t < -2147483648.0 || t > 2147483647.0) return false;
-  *out = (int32_t)t;
+  if (!(t > -2147483649.0 && t < 2147483648.0)) return false;   // NaN fails both
+  *out = (int32_t)t;   // the conversion truncates towards zero
   return true;
 }
 
@@ -90,8 +88,13 @@ inline bool cluster_coord(int32_t c, int downscale, const Scale &s, int32_t *out
   return to_int(t + s.offset, out);
 }
 
+// threads are started per call, which costs more than formatting a few thousand points:
+// `work` (points of the whole batch) below WORK_PER_THREAD a thread keeps the call serial
+constexpr long long WORK_PER_THREAD = 16384;
+
 template <typename F>
-void for_images(int B, int threads, F f) {
+void for_images(int B, int threads, long long work, F f) {
+  if ((long long)threads > work / WORK_PER_THREAD) threads = (int)(work / WORK_PER_THREAD);
   if (threads <= 1 || B < 2 * threads) {
     for (int b = 0; b < B; ++b) f(b);
     return;
@@ -106,6 +109,16 @@ void for_images(int B, int threads, F f) {
 
 // decimal text of an int followed by ".00": what "{:.2f}".format(int) prints
 inline char *put_int_2f(char *p, int32_t v) {
+  if (v >= 0 && v < 10000) {   // pixel coordinates: at most four digits
+    if (v >= 1000) *p++ = (char)('0' + v / 1000);
+    if (v >= 100) *p++ = (char)('0' + v / 100 % 10);
+    if (v >= 10) *p++ = (char)('0' + v / 10 % 10);
+    *p++ = (char)('0' + v % 10);
+    *p++ = '.';
+    *p++ = '0';
+    *p++ = '0';
+    return p;
+  }
   char tmp[16];
   int n = 0;
   long long a = v;
@@ -134,9 +147,11 @@ extern "C" int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_f
   const Scale sx = {(f->crop_x1 - f->crop_x0) / (double)f->img_w, f->crop_x0, f->float32_scalars};
   const Scale sy = {(f->crop_y1 - f->crop_y0) / (double)f->img_h, f->crop_y0, f->float32_scalars};
 
+  long long work = 0;
+  for (int b = 0; b < B; ++b) work += packed[(size_t)b * 8];
   // pass 1: members per group -> lanes kept and words per image
   std::vector<int> words(B, 0), nlanes(B, 0), bad(B, 0);
-  for_images(B, f->threads, [&](int b) {
+  for_images(B, f->threads, work, [&](int b) {
     ImageView v;
     if (!view_image(packed, B, b, f->by_center, &v)) {
       bad[b] = 1;
@@ -176,7 +191,7 @@ extern "C" int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_f
   }
 
   // pass 2: the lanes in group order, their points in keypoint order
-  for_images(B, f->threads, [&](int b) {
+  for_images(B, f->threads, work, [&](int b) {
     ImageView v;
     view_image(packed, B, b, f->by_center, &v);
     int32_t *rec = lanes + (size_t)B * 4 + lanes[(size_t)b * 4 + 2];
@@ -225,7 +240,7 @@ extern "C" int ganet_tusimple_from_lanes(const int32_t *lanes, int B, const int3
   lane_start[0] = 0;
   for (int b = 0; b < B; ++b) lane_start[b + 1] = lane_start[b] + lanes[(size_t)b * 4];
   if (xs_words < (size_t)lane_start[B] * (size_t)n_h) return GANET_ERR_WORKSPACE;
-  for_images(B, threads, [&](int b) {
+  for_images(B, threads, (long long)lane_start[B] * n_h * 4, [&](int b) {
     const int32_t *rec = lanes + (size_t)B * 4 + lanes[(size_t)b * 4 + 2];
     int pos = 0;
     for (int l = 0; l < lanes[(size_t)b * 4]; ++l) {
@@ -272,7 +287,7 @@ extern "C" int ganet_culane_text(const int32_t *lanes, int B, int threads, char 
   }
   if (!text || text_bytes < text_start[B]) return GANET_ERR_WORKSPACE;
   std::vector<size_t> used(B, 0);
-  for_images(B, threads, [&](int b) {
+  for_images(B, threads, (long long)(text_start[B] / 30), [&](int b) {
     const int32_t *rec = lanes + (size_t)B * 4 + lanes[(size_t)b * 4 + 2];
     char *p = text + text_start[b];
     int pos = 0;

@@ -241,8 +241,9 @@ class BatchLanes(object):
                                 raw_file=raw_files[b], run_time=run_time))
                 for b in range(self.B)]
 
-    def culane_texts(self):
-        """The `.lines.txt` text of every image (culane/test_dataset.py:138-148)."""
+    def culane_text_buffer(self):
+        """The `.lines.txt` texts of the batch in one buffer: (bytes-like uint8 array,
+        start [B], length [B]); image b's text is buf[start[b]:start[b] + length[b]]."""
         L = _lib.lib()
         start = np.zeros(2 * self.B + 1, np.uint64)
         L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads, None, 0,
@@ -251,9 +252,13 @@ class BatchLanes(object):
         rc = L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads, buf.ctypes.data,
                                  buf.size, start.ctypes.data)
         _lib.check(rc, "ganet_culane_text")
+        return buf, start[:self.B].astype(np.int64), start[self.B + 1:].astype(np.int64)
+
+    def culane_texts(self):
+        """The `.lines.txt` text of every image (culane/test_dataset.py:138-148)."""
+        buf, start, length = self.culane_text_buffer()
         raw = buf.tobytes()
-        return [raw[int(start[b]):int(start[b]) + int(start[self.B + 1 + b])].decode("ascii")
-                for b in range(self.B)]
+        return [raw[s:s + n].decode("ascii") for s, n in zip(start.tolist(), length.tolist())]
 
 
 def format_batch(packed, B, by_center, downscale, crop_bbox, img_shape, points_thr, threads=0):

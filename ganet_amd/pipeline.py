@@ -246,7 +246,7 @@ class HotPath(object):
             slot["host"][bufs.budget:total].copy_(bufs.packed[bufs.budget:total])
         return host, total
 
-    def packed(self, slot):
+    def records(self, slot):
         """The record stream of a step (header + records, the layout of ganet_decode_pack)
         as a view of the pinned host block - the input of formats.format_batch.  Waits for
         that step only; valid until the step after next reuses the block."""

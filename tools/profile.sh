@@ -26,9 +26,6 @@ run pmc_sq2 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_L
 run pmc_l1 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE || exit 1
 python3 "$REPO/tools/prof_summarize.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
-# measured traffic of this workload into profiles/pmc_traffic.json (TRAFFIC_KEY=c3_bf16 ...);
-# LFA calls of the profiled run = spin-up (300, warm-up included) + 20 timed steps
-if [ -n "${TRAFFIC_KEY:-}" ]; then
-  cp "$OUT/summary.txt" "$REPO/profiles/${TAG}_rocprofv3_summary.txt"
-  python3 "$REPO/tools/traffic_json.py" "$TAG" "$TRAFFIC_KEY" "${LFA_CALLS:-320}"
-fi
+# Back in the build container (gpurun merges gpurun_out/ only):
+#   cp gpurun_out/prof_<tag>/summary.txt profiles/<tag>_rocprofv3_summary.txt
+#   python tools/traffic_json.py <tag> <key, e.g. c3_bf16> 320   # LFA calls of the run: 300 spin-up + 20
