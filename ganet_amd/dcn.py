@@ -7,8 +7,13 @@ exception behaviour as the reference:
   ModulatedDeformConvFunction / modulated_deform_conv   :114-184, 188
   DeformConv :191-253, DeformConv1D :255-317, DeformConvPack :320-387
   ModulatedDeformConv :390-437, ModulatedDeformConvPack :440-512
-The forward runs the fused HIP kernel (csrc/deform_conv.hip); there is no
-eager / CPU fallback.  Backward is not built yet (inference path): it raises.
+Only names, signatures, attribute names, state-dict keys and exception types/messages
+are the reference's (they are the drop-in contract); the bodies are written against the
+C-ABI.  Forward and backward run the HIP kernels (csrc/deform_conv*.hip); there is no
+eager / CPU fallback: CPU tensors raise NotImplementedError like the reference.  The backward
+takes float32 tensors only (the reference also dispatches half there).
+'DCN' / 'DCNv2' are registered with mmcv's CONV_LAYERS only on request:
+register_with_mmcv().
 """
 import ctypes
 import math
@@ -55,8 +60,14 @@ _PACKED_MAX = 32
 def _packed_weight(L, weight, p):
     """Weights repacked for the kernel ([tap][Cout][Cin]); cached while the
     parameter is unchanged (inference: one pack per module, not per call)."""
+    # the packed layout depends on the algorithm the library picks for `p` (plain
+    # [tap][Cout][Cin], or hi/lo bf16 planes for the split float32 GEMM), so the choice and
+    # the packed size are part of the key, next to the tensor's identity
     key = (weight.data_ptr(), weight._version, weight.dtype, weight.device,
-           tuple(weight.shape), p.mfma_bf16, p.deformable_groups)
+           tuple(weight.shape), p.mfma_bf16, p.deformable_groups, p.algo,
+           L.ganet_deform_conv_algorithm(ctypes.byref(p)),
+           L.ganet_deform_conv_packed_weight_bytes(ctypes.byref(p)),
+           (p.B, p.H, p.W, p.sH, p.sW, p.x_layout))
     hit = _PACKED.get(key)
     if hit is not None:
         return hit
@@ -243,141 +254,130 @@ def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
     return grad_input, grad_offset, grad_mask, grad_weight, grad_bias
 
 
+def _conv_out_hw(size_hw, kernel_hw, stride, padding, dilation):
+    """Output height/width by the library's rule (ganet_dcn_out_size =
+    deform_conv.py:98-111); 0 where Python's floor division would not be positive."""
+    L = _lib.lib()
+    return tuple(L.ganet_dcn_out_size(int(size_hw[d]), int(padding[d]), int(dilation[d]),
+                                      int(kernel_hw[d]), int(stride[d])) for d in (0, 1))
+
+
+def _check_im2col_step(im2col_step, batch):
+    # the kernels do not chunk the batch; the reference's divisibility contract is kept
+    # for API parity (deform_conv.py:49-51)
+    assert batch % min(im2col_step, batch) == 0, 'im2col step must divide batchsize'
+
+
 class DeformConvFunction(Function):
 
     @staticmethod
-    def forward(ctx,
-                input,
-                offset,
-                weight,
-                stride=1,
-                padding=0,
-                dilation=1,
-                groups=1,
-                deformable_groups=1,
-                im2col_step=64):
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1,
+                deformable_groups=1, im2col_step=64):
         if input is not None and input.dim() != 4:
             raise ValueError(f'Expected 4D tensor as input, got {input.dim()}'
                              'D tensor instead.')
-        ctx.stride = _pair(stride)
-        ctx.padding = _pair(padding)
-        ctx.dilation = _pair(dilation)
-        ctx.groups = groups
-        ctx.deformable_groups = deformable_groups
+        ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        ctx.groups, ctx.deformable_groups = groups, deformable_groups
         ctx.im2col_step = im2col_step
         ctx.save_for_backward(input, offset, weight)
-
-        # raises ValueError for empty outputs exactly like the reference
-        DeformConvFunction._output_size(input, weight, ctx.padding,
-                                        ctx.dilation, ctx.stride)
+        # same order of complaints as the reference: empty output, CPU tensor, im2col step
+        DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride)
         if not input.is_cuda:
             raise NotImplementedError
-        # the fused kernel has no im2col chunking; the divisibility contract
-        # of the reference API is kept (deform_conv.py:49-51)
-        cur_im2col_step = min(ctx.im2col_step, input.shape[0])
-        assert (input.shape[0] %
-                cur_im2col_step) == 0, 'im2col step must divide batchsize'
-        return deform_conv_forward(input, offset, weight, ctx.stride,
-                                   ctx.padding, ctx.dilation, ctx.groups,
-                                   ctx.deformable_groups)
+        _check_im2col_step(im2col_step, input.shape[0])
+        return deform_conv_forward(input, offset, weight, ctx.stride, ctx.padding,
+                                   ctx.dilation, groups, deformable_groups)
 
     @staticmethod
     def backward(ctx, grad_output):
-        # deform_conv.py:60-96
+        # deform_conv.py:60-96: gradients of input, offset and weight, None for the rest
         input, offset, weight = ctx.saved_tensors
         if not grad_output.is_cuda:
             raise NotImplementedError
-        cur_im2col_step = min(ctx.im2col_step, input.shape[0])
-        assert (input.shape[0] %
-                cur_im2col_step) == 0, 'im2col step must divide batchsize'
-        need_input = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        need_weight = ctx.needs_input_grad[2]
-        grad_input, grad_offset, _, grad_weight, _ = deform_conv_backward(
+        _check_im2col_step(ctx.im2col_step, input.shape[0])
+        want = ctx.needs_input_grad
+        g_in, g_off, _, g_w, _ = deform_conv_backward(
             input, offset, weight, grad_output, ctx.stride, ctx.padding, ctx.dilation,
-            ctx.groups, ctx.deformable_groups, need_input=need_input,
-            need_weight=need_weight)
-        return (grad_input, grad_offset, grad_weight, None, None, None, None,
-                None, None)
+            ctx.groups, ctx.deformable_groups, need_input=want[0] or want[1],
+            need_weight=want[2])
+        return (g_in, g_off, g_w) + (None,) * 6
 
     @staticmethod
     def _output_size(input, weight, padding, dilation, stride):
-        channels = weight.size(0)
-        output_size = (input.size(0), channels)
-        for d in range(input.dim() - 2):
-            in_size = input.size(d + 2)
-            pad = padding[d]
-            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
-            stride_ = stride[d]
-            output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1, )
-        if not all(map(lambda s: s > 0, output_size)):
+        """(B, Cout, Hout, Wout); ValueError with the reference's text if a side is < 1."""
+        hw = _conv_out_hw(input.shape[2:], weight.shape[2:], stride, padding, dilation)
+        shape = (input.size(0), weight.size(0)) + hw
+        if min(shape) <= 0:
+            # the message shows Python's floor-division sizes, as the reference's does
+            shown = shape[:2] + tuple(
+                (input.size(d + 2) + 2 * padding[d]
+                 - (dilation[d] * (weight.size(d + 2) - 1) + 1)) // stride[d] + 1
+                for d in (0, 1))
             raise ValueError('convolution input is too small (output would be '
-                             f'{"x".join(map(str, output_size))})')
-        return output_size
+                             + 'x'.join(str(v) for v in shown) + ')')
+        return shape
 
 
 class ModulatedDeformConvFunction(Function):
 
     @staticmethod
-    def forward(ctx,
-                input,
-                offset,
-                mask,
-                weight,
-                bias=None,
-                stride=1,
-                padding=0,
-                dilation=1,
-                groups=1,
-                deformable_groups=1):
-        ctx.stride = stride
-        ctx.padding = padding
-        ctx.dilation = dilation
-        ctx.groups = groups
-        ctx.deformable_groups = deformable_groups
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1,
+                groups=1, deformable_groups=1):
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation
+        ctx.groups, ctx.deformable_groups = groups, deformable_groups
         ctx.with_bias = bias is not None
-        if not ctx.with_bias:
-            bias = input.new_empty(1)  # fake tensor, as the reference (deform_conv.py:131)
         if not input.is_cuda:
             raise NotImplementedError
-        if weight.requires_grad or mask.requires_grad or offset.requires_grad \
-                or input.requires_grad:
-            ctx.save_for_backward(input, offset, mask, weight, bias)
-        if not ctx.with_bias:
-            bias = None
-        return deform_conv_forward(input, offset, weight, _pair(stride),
-                                   _pair(padding), _pair(dilation), groups,
-                                   deformable_groups, mask=mask, bias=bias)
+        if any(t.requires_grad for t in (input, offset, mask, weight)):
+            # five saved tensors like the reference, which stores a one-element stand-in
+            # when there is no bias (deform_conv.py:130-137)
+            ctx.save_for_backward(input, offset, mask, weight,
+                                  bias if ctx.with_bias else input.new_empty(1))
+        return deform_conv_forward(input, offset, weight, _pair(stride), _pair(padding),
+                                   _pair(dilation), groups, deformable_groups, mask=mask,
+                                   bias=bias)
 
     @staticmethod
     def backward(ctx, grad_output):
         # deform_conv.py:152-172
         if not grad_output.is_cuda:
             raise NotImplementedError
-        input, offset, mask, weight, bias = ctx.saved_tensors
-        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = deform_conv_backward(
+        input, offset, mask, weight, _bias = ctx.saved_tensors
+        grads = deform_conv_backward(
             input, offset, weight, grad_output, _pair(ctx.stride), _pair(ctx.padding),
             _pair(ctx.dilation), ctx.groups, ctx.deformable_groups, mask=mask,
             need_input=True, need_weight=True, need_bias=ctx.with_bias)
-        if not ctx.with_bias:
-            grad_bias = None
-        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias,
-                None, None, None, None, None)
+        g_in, g_off, g_mask, g_w, g_b = grads
+        return (g_in, g_off, g_mask, g_w, g_b if ctx.with_bias else None) + (None,) * 5
 
     @staticmethod
     def _infer_shape(ctx, input, weight):
-        n = input.size(0)
-        channels_out = weight.size(0)
-        height, width = input.shape[2:4]
-        kernel_h, kernel_w = weight.shape[2:4]
-        height_out = (height + 2 * ctx.padding -
-                      (ctx.dilation * (kernel_h - 1) + 1)) // ctx.stride + 1
-        width_out = (width + 2 * ctx.padding -
-                     (ctx.dilation * (kernel_w - 1) + 1)) // ctx.stride + 1
-        return n, channels_out, height_out, width_out
+        hw = _conv_out_hw(input.shape[2:4], weight.shape[2:4], _pair(ctx.stride),
+                          _pair(ctx.padding), _pair(ctx.dilation))
+        return (input.size(0), weight.size(0)) + hw
 
 
 deform_conv = DeformConvFunction.apply
 modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+def _set_conv_attributes(m, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, deformable_groups):
+    """Attribute names of the reference modules (and the two nn.Conv2d look-alikes mmcv's
+    wrappers read), the `weight` parameter [Cout, Cin/groups, kH, kW]."""
+    m.in_channels, m.out_channels = in_channels, out_channels
+    m.kernel_size, m.stride, m.padding, m.dilation = kernel_size, stride, padding, dilation
+    m.groups, m.deformable_groups = groups, deformable_groups
+    m.transposed = False
+    m.output_padding = _single(0)
+    m.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *kernel_size))
+
+
+def _uniform_fan_in(m):
+    """weight ~ U(+-1/sqrt(Cin * kH * kW)) (deform_conv.py:225-230, :294-299, :423-430)."""
+    bound = 1.0 / math.sqrt(m.in_channels * m.kernel_size[0] * m.kernel_size[1])
+    with torch.no_grad():
+        m.weight.uniform_(-bound, bound)
 
 
 class _DeformConvBase(nn.Module):
@@ -391,45 +391,25 @@ class _DeformConvBase(nn.Module):
         assert out_channels % groups == 0, \
             f'out_channels {out_channels} is not divisible ' \
             f'by groups {groups}'
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = kernel_size
-        self.stride = stride
-        self.padding = padding
-        self.dilation = dilation
-        self.groups = groups
-        self.deformable_groups = deformable_groups
-        # enable compatibility with nn.Conv2d
-        self.transposed = False
-        self.output_padding = _single(0)
-        self.weight = nn.Parameter(
-            torch.Tensor(out_channels, in_channels // self.groups,
-                         *self.kernel_size))
+        _set_conv_attributes(self, in_channels, out_channels, kernel_size, stride, padding,
+                             dilation, groups, deformable_groups)
         self.reset_parameters()
 
     def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        _uniform_fan_in(self)
 
     def forward(self, x, offset):
-        # input image smaller than the kernel: pad, run, crop
-        # (deform_conv.py:237-253 / :301-317)
-        input_pad = (
-            x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1])
-        if input_pad:
-            pad_h = max(self.kernel_size[0] - x.size(2), 0)
-            pad_w = max(self.kernel_size[1] - x.size(3), 0)
-            x = F.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
-            offset = F.pad(offset, (0, pad_w, 0, pad_h), 'constant',
-                           0).contiguous()
+        # A map smaller than the kernel is zero-padded at the bottom/right up to the kernel
+        # size (offsets alike) and the result cropped back (deform_conv.py:237-253, :301-317).
+        grow_h = max(self.kernel_size[0] - x.size(2), 0)
+        grow_w = max(self.kernel_size[1] - x.size(3), 0)
+        if grow_h or grow_w:
+            x = F.pad(x, (0, grow_w, 0, grow_h)).contiguous()
+            offset = F.pad(offset, (0, grow_w, 0, grow_h)).contiguous()
         out = deform_conv(x, offset, self.weight, self.stride, self.padding,
                           self.dilation, self.groups, self.deformable_groups)
-        if input_pad:
-            out = out[:, :, :out.size(2) - pad_h, :out.size(3) -
-                      pad_w].contiguous()
+        if grow_h or grow_w:
+            out = out[:, :, :out.size(2) - grow_h, :out.size(3) - grow_w].contiguous()
         return out
 
 
@@ -456,51 +436,49 @@ class DeformConv1D(_DeformConvBase):
                    (0, padding), (1, dilation), groups, deformable_groups, bias)
 
 
-class DeformConvPack(DeformConv):
-    """Deformable conv that predicts its own offsets (deform_conv.py:320-387)."""
+class _OffsetPackMixin(object):
+    """The `conv_offset` branch of DeformConvPack / ModulatedDeformConvPack: an ordinary
+    convolution with the module's own geometry that predicts `maps_per_tap` values per
+    kernel tap and deformable group, zero-initialised (deform_conv.py:339-360, :455-484);
+    checkpoints older than version 2 call it `<name>_offset` (:362-377, :486-502)."""
 
     _version = 2
 
-    def __init__(self, *args, **kwargs):
-        super(DeformConvPack, self).__init__(*args, **kwargs)
-        self.conv_offset = nn.Conv2d(
-            self.in_channels,
-            self.deformable_groups * 2 * self.kernel_size[0] *
-            self.kernel_size[1],
-            kernel_size=self.kernel_size,
-            stride=_pair(self.stride),
-            padding=_pair(self.padding),
-            dilation=_pair(self.dilation),
-            bias=True)
+    def _add_conv_offset(self, maps_per_tap):
+        taps = self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset = nn.Conv2d(self.in_channels,
+                                     self.deformable_groups * maps_per_tap * taps,
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                     padding=_pair(self.padding),
+                                     dilation=_pair(self.dilation), bias=True)
         self.init_offset()
 
     def init_offset(self):
-        self.conv_offset.weight.data.zero_()
-        self.conv_offset.bias.data.zero_()
-
-    def forward(self, x):
-        offset = self.conv_offset(x)
-        return deform_conv(x, offset, self.weight, self.stride, self.padding,
-                           self.dilation, self.groups, self.deformable_groups)
+        for t in (self.conv_offset.weight, self.conv_offset.bias):
+            nn.init.zeros_(t)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict,
                               missing_keys, unexpected_keys, error_msgs):
-        _migrate_offset_keys(state_dict, prefix, local_metadata)
-        super()._load_from_state_dict(state_dict, prefix, local_metadata,
-                                      strict, missing_keys, unexpected_keys,
-                                      error_msgs)
+        version = local_metadata.get('version', None)
+        if version is None or version < 2:
+            for leaf in ('weight', 'bias'):
+                new, old = prefix + 'conv_offset.' + leaf, prefix[:-1] + '_offset.' + leaf
+                if new not in state_dict and old in state_dict:
+                    state_dict[new] = state_dict.pop(old)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict,
+                                      missing_keys, unexpected_keys, error_msgs)
 
 
-def _migrate_offset_keys(state_dict, prefix, local_metadata):
-    """Version < 2 checkpoints name the offset conv `<name>_offset`
-    (deform_conv.py:362-377, :486-502)."""
-    version = local_metadata.get('version', None)
-    if version is None or version < 2:
-        for leaf in ('weight', 'bias'):
-            new = prefix + 'conv_offset.' + leaf
-            old = prefix[:-1] + '_offset.' + leaf
-            if new not in state_dict and old in state_dict:
-                state_dict[new] = state_dict.pop(old)
+class DeformConvPack(_OffsetPackMixin, DeformConv):
+    """Deformable conv that predicts its own offsets (deform_conv.py:320-387)."""
+
+    def __init__(self, *args, **kwargs):
+        super(DeformConvPack, self).__init__(*args, **kwargs)
+        self._add_conv_offset(2)          # (dy, dx) per tap
+
+    def forward(self, x):
+        return deform_conv(x, self.conv_offset(x), self.weight, self.stride, self.padding,
+                           self.dilation, self.groups, self.deformable_groups)
 
 
 class ModulatedDeformConv(nn.Module):
@@ -509,36 +487,20 @@ class ModulatedDeformConv(nn.Module):
                  padding=0, dilation=1, groups=1, deformable_groups=1,
                  bias=True):
         super(ModulatedDeformConv, self).__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = _pair(kernel_size)
-        self.stride = stride
-        self.padding = padding
-        self.dilation = dilation
-        self.groups = groups
-        self.deformable_groups = deformable_groups
+        # stride / padding / dilation stay as given (ints), as the reference keeps them
+        _set_conv_attributes(self, in_channels, out_channels, _pair(kernel_size), stride,
+                             padding, dilation, groups, deformable_groups)
         self.with_bias = bias
-        # enable compatibility with nn.Conv2d
-        self.transposed = False
-        self.output_padding = _single(0)
-
-        self.weight = nn.Parameter(
-            torch.Tensor(out_channels, in_channels // groups,
-                         *self.kernel_size))
         if bias:
-            self.bias = nn.Parameter(torch.Tensor(out_channels))
+            self.bias = nn.Parameter(torch.empty(out_channels))
         else:
             self.register_parameter('bias', None)
         self.reset_parameters()
 
     def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        _uniform_fan_in(self)
         if self.bias is not None:
-            self.bias.data.zero_()
+            nn.init.zeros_(self.bias)
 
     def forward(self, x, offset, mask):
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
@@ -546,54 +508,30 @@ class ModulatedDeformConv(nn.Module):
                                      self.groups, self.deformable_groups)
 
 
-class ModulatedDeformConvPack(ModulatedDeformConv):
-
-    _version = 2
+class ModulatedDeformConvPack(_OffsetPackMixin, ModulatedDeformConv):
 
     def __init__(self, *args, **kwargs):
         super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
-        self.conv_offset = nn.Conv2d(
-            self.in_channels,
-            self.deformable_groups * 3 * self.kernel_size[0] *
-            self.kernel_size[1],
-            kernel_size=self.kernel_size,
-            stride=_pair(self.stride),
-            padding=_pair(self.padding),
-            dilation=_pair(self.dilation),
-            bias=True)
-        self.init_offset()
-
-    def init_offset(self):
-        self.conv_offset.weight.data.zero_()
-        self.conv_offset.bias.data.zero_()
+        self._add_conv_offset(3)          # (dy, dx, mask logit) per tap
 
     def forward(self, x):
-        out = self.conv_offset(x)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
+        # channel thirds: y offsets, x offsets, mask logits (deform_conv.py:476-484)
+        planes = self.conv_offset(x)
+        third = planes.size(1) // 3
+        offset, logits = planes[:, :2 * third], planes[:, 2 * third:]
+        return modulated_deform_conv(x, offset, logits.sigmoid(), self.weight, self.bias,
                                      self.stride, self.padding, self.dilation,
                                      self.groups, self.deformable_groups)
 
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict,
-                              missing_keys, unexpected_keys, error_msgs):
-        _migrate_offset_keys(state_dict, prefix, local_metadata)
-        super()._load_from_state_dict(state_dict, prefix, local_metadata,
-                                      strict, missing_keys, unexpected_keys,
-                                      error_msgs)
 
-
-def _register_with_mmcv():
-    """Register 'DCN' / 'DCNv2' with mmcv's CONV_LAYERS when mmcv is present
-    (deform_conv.py:320, :440); a no-op otherwise."""
+def register_with_mmcv(force=False):
+    """Register DeformConvPack / ModulatedDeformConvPack as 'DCN' / 'DCNv2' in mmcv's
+    CONV_LAYERS (deform_conv.py:320, :440).  An explicit call, not an import side effect;
+    force=True replaces an existing registration.  False when mmcv is absent."""
     try:
         from mmcv.cnn import CONV_LAYERS
     except Exception:
         return False
-    CONV_LAYERS.register_module('DCN', module=DeformConvPack, force=True)
-    CONV_LAYERS.register_module('DCNv2', module=ModulatedDeformConvPack, force=True)
+    CONV_LAYERS.register_module('DCN', module=DeformConvPack, force=force)
+    CONV_LAYERS.register_module('DCNv2', module=ModulatedDeformConvPack, force=force)
     return True
-
-
-_register_with_mmcv()

@@ -14,7 +14,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .dcn import DeformConv1D, deform_conv_forward
+from torch.autograd import Function
+
+from .dcn import DeformConv1D, deform_conv_backward, deform_conv_forward
 
 
 def dcn_base_offset(num_points, dtype=torch.float32, device=None):
@@ -23,6 +25,36 @@ def dcn_base_offset(num_points, dtype=torch.float32, device=None):
     base = np.arange(-pad, pad + 1).astype(np.float64)
     off = np.stack([np.repeat(0, num_points), np.tile(base, 1)], axis=1).reshape(-1)
     return torch.tensor(off).reshape(1, -1, 1, 1).to(dtype=dtype, device=device)
+
+
+class _FusedLfaTail(Function):
+    """relu(DeformConv1D(x, pts - base)) as ONE forward call with gradients: the backward
+    masks grad_output with the ReLU (out > 0) and runs ganet_deform_conv_backward on
+    offset = pts - base; d(offset)/d(pts) = 1, so the offset gradient is the gradient of
+    `pts_out_init` (which the reference trains through, lanepoints_conv.py:159-172)."""
+
+    @staticmethod
+    def forward(ctx, cls_feat, pts_out_init, weight, stride, padding, dilation, num_points):
+        out = deform_conv_forward(cls_feat, pts_out_init, weight, stride, padding, dilation,
+                                  1, 1, fuse_relu=True, offset_is_points=True)
+        ctx.geometry = (stride, padding, dilation, num_points)
+        ctx.save_for_backward(cls_feat, pts_out_init, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        cls_feat, pts, weight, out = ctx.saved_tensors
+        stride, padding, dilation, num_points = ctx.geometry
+        grad_pre = (grad_output * (out > 0).to(grad_output.dtype)).contiguous(
+            memory_format=torch.channels_last if out.is_contiguous(
+                memory_format=torch.channels_last) and not out.is_contiguous()
+            else torch.contiguous_format)
+        offset = (pts - dcn_base_offset(num_points, pts.dtype, pts.device)).contiguous()
+        want = ctx.needs_input_grad
+        g_in, g_off, _, g_w, _ = deform_conv_backward(
+            cls_feat, offset, weight, grad_pre, stride, padding, dilation, 1, 1,
+            need_input=want[0] or want[1], need_weight=want[2])
+        return g_in, g_off, g_w, None, None, None, None
 
 
 class LaneAwareAggregator(nn.Module):
@@ -42,10 +74,14 @@ class LaneAwareAggregator(nn.Module):
                                  1, self.dcn_pad)
 
     def forward(self, cls_feat, pts_out_init):
-        return deform_conv_forward(
-            cls_feat, pts_out_init, self.conv.weight, self.conv.stride,
-            self.conv.padding, self.conv.dilation, 1, 1, fuse_relu=True,
-            offset_is_points=True)
+        c = self.conv
+        if torch.is_grad_enabled() and (cls_feat.requires_grad or pts_out_init.requires_grad
+                                        or c.weight.requires_grad):
+            # training: the same fused forward, recorded for autograd
+            return _FusedLfaTail.apply(cls_feat, pts_out_init, c.weight, c.stride, c.padding,
+                                       c.dilation, self.num_points)
+        return deform_conv_forward(cls_feat, pts_out_init, c.weight, c.stride, c.padding,
+                                   c.dilation, 1, 1, fuse_relu=True, offset_is_points=True)
 
     def forward_unfused(self, cls_feat, pts_out_init):
         """The reference's three-step form (for parity tests)."""

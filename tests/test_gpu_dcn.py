@@ -304,3 +304,35 @@ def test_fused_lfa_tail_matches_unfused():
     assert torch.equal(fused, unfused)   # same kernel arithmetic, bit for bit
     ref = np.maximum(O.deform_conv_forward(x, off, w, (1, 1), (0, 3), (1, 1), nthreads=8), 0)
     assert rel_err(fused.cpu().numpy(), ref) <= TOL_F32
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_fused_lfa_tail_gradients_match_unfused(channels_last):
+    """Training through LaneAwareAggregator: the fused forward is recorded for autograd and
+    gives cls_feat, pts_out_init and conv.weight the gradients of the reference's three-step
+    form (subtract, DeformConv1D, ReLU: lanepoints_conv.py:170-172)."""
+    agg = lfa.LaneAwareAggregator(256, 64, 7).cuda()
+    x, off, w, pts = synth.lfa_inputs(2, 256, 20, 30, 7, seed=6)
+    with torch.no_grad():
+        agg.conv.weight.copy_(torch.from_numpy(w))
+    go = torch.randn(2, 64, 20, 30, device="cuda")
+    grads = []
+    for fn in (agg.forward, agg.forward_unfused):
+        xt = torch.from_numpy(x).cuda()
+        if channels_last:
+            xt = xt.contiguous(memory_format=torch.channels_last)
+        xt.requires_grad_(True)
+        pt = torch.from_numpy(pts).cuda().requires_grad_(True)
+        agg.conv.weight.grad = None
+        out = fn(xt, pt)
+        assert out.grad_fn is not None
+        out.backward(go)
+        grads.append((out.detach(), xt.grad, pt.grad, agg.conv.weight.grad.clone()))
+    (o1, gx1, gp1, gw1), (o2, gx2, gp2, gw2) = grads
+    assert torch.equal(o1, o2)
+    for a, b in ((gx1, gx2), (gp1, gp2), (gw1, gw2)):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-4 * scale
+    # inference keeps the raw call: no graph is recorded
+    with torch.no_grad():
+        assert agg(torch.from_numpy(x).cuda(), torch.from_numpy(pts).cuda()).grad_fn is None
