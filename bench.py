@@ -50,6 +50,9 @@ WORKLOADS = {
     "c5": dict(shape="dense_s8", B=32, Cin=256, dtype="bf16", decode=True,
                desc="C5 dense stress: 1280x3200 frames (160x400 @ s8), 16 lanes, thr 0.05, "
                     "batch 32 per GPU (256 over 8)"),
+    "c5_s4": dict(shape="dense_s4", B=32, Cin=256, dtype="bf16", decode=True,
+                  desc="C5 dense stress at stride 4: 1280x3200 frames (320x800 @ s4), K9, 16 lanes, "
+                       "thr 0.05, batch 32 per GPU (256 over 8); one image per Y chunk"),
 }
 TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}
 ESIZE = {"bf16": 2, "f16": 2, "fp32": 4}
@@ -314,7 +317,8 @@ def main():
     T = float(cfg["T"])
     hp = HotPath(B, H, W, Cin=Cin, Cout=64, K=K, dtype=TORCH_DTYPE[dtype], device=dev,
                  thr=cfg["thr"], root_thr=cfg["root_thr"], cluster_thr=T, by_center_thr=T,
-                 max_kpts=min(H * W, 4096 if cfg["lanes"] > 4 else 1024),
+                 max_kpts=min(H * W, 8192 if H * W > 64000 else
+                              (4096 if cfg["lanes"] > 4 else 1024)),
                  max_centers=256, overlap_copy=args.overlap_copy,
                  mfma_bf16={"auto": 0, "bf16": 1, "exact": 2}[args.fp32_mode],
                  side_decode=wl["decode"] and not (args.single_stream or args.graph

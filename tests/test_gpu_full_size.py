@@ -26,10 +26,11 @@ def lfa(xt, pt, wt, K):
     return out
 
 
-def inputs(B, H, W, K, dtype, nseed=8, seed=0):
+def inputs(B, H, W, K, dtype, nseed=8, seed=0, Cin=256):
     """B images built from `nseed` seeded ones (each scaled differently so no two are
     equal): the generator costs more than the kernels at these sizes."""
-    x, off, w, pts = synth.lfa_inputs(nseed, 256, H, W, K, seed=seed)
+    nseed = min(nseed, B)
+    x, off, w, pts = synth.lfa_inputs(nseed, Cin, H, W, K, seed=seed)
     reps = (B + nseed - 1) // nseed
     scale = (1.0 + 0.03125 * np.arange(reps, dtype=np.float32)).repeat(nseed)[:B]
     xt = torch.from_numpy(x).cuda().repeat(reps, 1, 1, 1)[:B] * torch.from_numpy(scale).cuda()[:, None, None, None]
@@ -50,14 +51,18 @@ def oracle_images(xt, pts, wt, K, idx):
     return np.maximum(ref, 0)
 
 
-@pytest.mark.parametrize("name,B,H,W,K,dtype,tol,sample", [
-    ("c3", 128, 40, 100, 7, torch.bfloat16, 1e-2, None),      # whole batch against the oracle
-    ("c2", 32, 40, 100, 7, torch.float32, 1e-4, None),
-    ("c4", 128, 80, 200, 9, torch.bfloat16, 1e-2, [0, 6, 7, 63, 64, 127]),
-    ("c5", 32, 160, 400, 7, torch.bfloat16, 1e-2, [0, 15, 31]),
+@pytest.mark.parametrize("name,B,H,W,K,dtype,tol,sample,Cin", [
+    ("c3", 128, 40, 100, 7, torch.bfloat16, 1e-2, None, 256),   # whole batch against the oracle
+    ("c2", 32, 40, 100, 7, torch.float32, 1e-4, None, 256),
+    ("c2_c64", 32, 40, 100, 7, torch.float32, 1e-4, None, 64),  # BASELINE config 2's "C=64"
+    ("c4", 128, 80, 200, 9, torch.bfloat16, 1e-2, [0, 6, 7, 63, 64, 127], 256),
+    ("c5", 32, 160, 400, 7, torch.bfloat16, 1e-2, [0, 15, 31], 256),
+    # C5 at stride 4: 320x800 maps, K 9 - one image's per-tap products are 295 MB, so
+    # every Y chunk is a single image
+    ("c5_s4", 4, 320, 800, 9, torch.bfloat16, 1e-2, [0, 3], 256),
 ])
-def test_full_size_against_oracle_and_permutation(name, B, H, W, K, dtype, tol, sample):
-    xt, pt, wt, pts = inputs(B, H, W, K, dtype)
+def test_full_size_against_oracle_and_permutation(name, B, H, W, K, dtype, tol, sample, Cin):
+    xt, pt, wt, pts = inputs(B, H, W, K, dtype, Cin=Cin)
     out = lfa(xt, pt, wt, K)
     idx = list(range(B)) if sample is None else sample
     ref = oracle_images(xt, pts, wt, K, idx)
