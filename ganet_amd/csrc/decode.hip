@@ -71,9 +71,13 @@ __device__ __forceinline__ float heat_nms(const float *__restrict__ img, int H, 
 
 __global__ __launch_bounds__(kBlock) void decode_mask_kernel(
     const float *__restrict__ heat, int HW, int W, float thr,
-    unsigned long long *__restrict__ kmask, int nwords, int rows3) {
+    unsigned long long *__restrict__ kmask, int nwords, int rows3,
+    int32_t *__restrict__ counts) {
   const int b = blockIdx.y;
   const int idx = blockIdx.x * kBlock + threadIdx.x;
+  // large images: decode_gather_kernel counts the centres in counts[b][1] by atomics
+  if (counts && blockIdx.x == 0 && threadIdx.x < GANET_DECODE_COUNT_STRIDE)
+    counts[(size_t)b * GANET_DECODE_COUNT_STRIDE + threadIdx.x] = 0;
   bool is_kpt = false;
   if (idx < HW) {
     const int y = idx / W;
@@ -127,10 +131,133 @@ struct DecodeArgs {
   ganet_decode_out out;
 };
 
-// DECODE: build the keypoint / centre lists from the bitmap (steps 1-2).
-// !DECODE: the lists already sit in the output arrays (ganet_group_batch).
-template <bool DECODE>
+// Large images (by-centre grouping): the keypoint lists of the whole batch on a grid of
+// workgroups instead of one workgroup per image.  Workgroup (chunk, image) owns 256 words of
+// the image's bitmap: it sums the popcounts of the words before its chunk (the keypoints'
+// row-major rank is an ORDERED count, no atomics), scans its own, and every thread gathers
+// the keypoints of its word.  Centres (offset_y < root_thr, ganet_head.py:213-216) go
+// unordered into centers_xy[slot] as packed (x << 16 | y) keys counted in counts[b][1]; the
+// group kernel rank-sorts them x-major, so their arrival order does not matter.
+__global__ __launch_bounds__(kBlock) void decode_gather_kernel(DecodeArgs a) {
+  __shared__ int wave_sums[kWavesPerBlock];
+  __shared__ int s_base;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int W = a.W;
+  const size_t HW = (size_t)a.H * W;
+  const float *off_x = a.offset + (size_t)b * 2 * HW;
+  const float *off_y = off_x + HW;
+  const float *err_x = a.error + (size_t)b * 2 * HW;
+  const float *err_y = err_x + HW;
+  const unsigned long long *kmask = a.kmask + (size_t)b * a.nwords;
+  int32_t *o_counts = a.out.counts + (size_t)b * GANET_DECODE_COUNT_STRIDE;
+  int32_t *o_cxy = a.out.centers_xy + (size_t)b * a.max_centers * 2;
+  int32_t *o_kxy = a.out.kpt_xy + (size_t)b * a.max_kpts * 2;
+  float *o_align = a.out.kpt_align + (size_t)b * a.max_kpts * 2;
+  float *o_root = a.out.kpt_root + (size_t)b * a.max_kpts * 2;
+  int32_t *o_kgid = a.out.kpt_gid + (size_t)b * a.max_kpts;
+
+  // keypoints in the words before this chunk
+  int before = 0;
+  for (int w = tid; w < chunk * kBlock; w += kBlock) before += __popcll(kmask[w]);
+  int total;
+  const int ex = block_excl_scan(before, wave_sums, &total);
+  (void)ex;
+  if (tid == 0) s_base = total;
+  __syncthreads();
+  const int base = s_base;
+  __syncthreads();
+
+  const int w = chunk * kBlock + tid;
+  unsigned long long bits = (w < a.nwords) ? kmask[w] : 0ull;
+  int pos = base + block_excl_scan(__popcll(bits), wave_sums, &total);
+  if (chunk == (int)gridDim.x - 1 && tid == 0) o_counts[0] = base + total;   // n_kpts
+  while (bits) {
+    const int bit = __ffsll((long long)bits) - 1;
+    bits &= bits - 1;
+    const int idx = w * 64 + bit;
+    const int y = idx / W, x = idx - y * W;
+    const float oy = off_y[idx], ox = off_x[idx], exx = err_x[idx], eyy = err_y[idx];
+    if (pos < a.max_kpts) {
+      const float fx = (float)x, fy = (float)y;
+      o_kxy[2 * pos] = x;
+      o_kxy[2 * pos + 1] = y;
+      o_root[2 * pos] = fx + ox;      // ganet_head.py:229
+      o_root[2 * pos + 1] = fy + oy;
+      o_align[2 * pos] = fx + exx;    // ganet_head.py:230
+      o_align[2 * pos + 1] = fy + eyy;
+      o_kgid[pos] = -1;
+    }
+    if (oy < a.root_thr) {
+      const int slot = atomicAdd(&o_counts[1], 1);
+      if (slot < a.max_centers) o_cxy[2 * slot] = (int)(((unsigned int)x << 16) | (unsigned int)y);
+    }
+    ++pos;
+  }
+}
+
+// Large images, after the group kernel: every keypoint to the first (flags bit2: nearest)
+// group centre within thr - step 5 of decode_group_kernel on a grid over the batch.
+__global__ __launch_bounds__(kBlock) void decode_assign_kernel(DecodeArgs a) {
+  __shared__ int s_gx[kBlock], s_gy[kBlock];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int32_t *o_counts = a.out.counts + (size_t)b * GANET_DECODE_COUNT_STRIDE;
+  const float *o_root = a.out.kpt_root + (size_t)b * a.max_kpts * 2;
+  int32_t *o_kgid = a.out.kpt_gid + (size_t)b * a.max_kpts;
+  const int32_t *o_gc = a.out.group_center + (size_t)b * a.max_groups * 2;
+  int32_t *o_gn = a.out.group_count + (size_t)b * a.max_groups;
+  const int nk_st = min(o_counts[0], a.max_kpts);
+  const int ng = min(o_counts[2], a.max_groups);   // more groups: flagged as overflow
+  if ((int)blockIdx.x * kBlock >= nk_st) return;    // uniform
+  const double T = a.by_center_thr;
+  const bool nearest = (a.flags & 4) != 0;
+  const int i = blockIdx.x * kBlock + tid;
+  const bool live = i < nk_st;
+  const double rx = live ? (double)o_root[2 * i] : 0.0, ry = live ? (double)o_root[2 * i + 1] : 0.0;
+  int found = -1;
+  double best = 0;
+  for (int g0 = 0; g0 < ng; g0 += kBlock) {
+    __syncthreads();
+    if (g0 + tid < ng) {
+      s_gx[tid] = o_gc[2 * (g0 + tid)];
+      s_gy[tid] = o_gc[2 * (g0 + tid) + 1];
+    }
+    __syncthreads();
+    const int n = min(kBlock, ng - g0);
+    for (int g = 0; g < n; ++g) {
+      if (found >= 0 && !nearest) break;
+      const double dx = rx - (double)s_gx[g];
+      const double dy = ry - (double)s_gy[g];
+      const double d = sqrt(dx * dx + dy * dy);
+      if (d <= T && (found < 0 || d < best)) {
+        found = g0 + g;
+        best = d;
+      }
+    }
+  }
+  if (live) o_kgid[i] = found;
+  // group sizes: a histogram in LDS per workgroup, then one global add per group (the
+  // keypoints of a lane are neighbours, so most of a workgroup adds to one or two groups)
+  if (ng <= kBlock) {
+    __syncthreads();
+    s_gx[tid] = 0;
+    __syncthreads();
+    if (live && found >= 0) atomicAdd(&s_gx[found], 1);
+    __syncthreads();
+    if (tid < ng && s_gx[tid]) atomicAdd(&o_gn[tid], s_gx[tid]);
+  } else if (live && found >= 0) {
+    atomicAdd(&o_gn[found], 1);
+  }
+}
+
+// MODE 0: build the keypoint / centre lists from the bitmap (steps 1-2), group, assign.
+// MODE 1: the lists already sit in the output arrays (ganet_group_batch).
+// MODE 2: large images - decode_gather_kernel wrote the keypoints and the unsorted centre
+//         keys; sort and cluster the centres here, decode_assign_kernel assigns afterwards.
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
+  constexpr bool DECODE = MODE == 0;
   // One LDS carve-up for both grouping modes (48 KiB).
   __shared__ int smem[6 * kMaxCenters];
   __shared__ int wave_sums[kWavesPerBlock];
@@ -307,6 +434,27 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     o_cxy[2 * i + 1] = (int)(ckey[i] & 0xffffu);
   }
 
+  } else if constexpr (MODE == 2) {
+    nk = o_counts[0];
+    nc_found = o_counts[1];
+    nk_st = min(nk, a.max_kpts);
+    nc = min(nc_found, min(a.max_centers, kMaxCenters));
+    overflow = (nk > a.max_kpts ? 1 : 0) |
+               (nc_found > min(a.max_centers, kMaxCenters) ? 2 : 0);
+    // x-major order by rank (ganet_head.py:217-219); keys are distinct pixels
+    for (int i = tid; i < nc; i += kBlock) ckey_raw[i] = (unsigned int)o_cxy[2 * i];
+    __syncthreads();
+    for (int i = tid; i < nc; i += kBlock) {
+      const unsigned int ki = ckey_raw[i];
+      int rank = 0;
+      for (int j = 0; j < nc; ++j) rank += (ckey_raw[j] < ki);
+      ckey[rank] = ki;
+    }
+    __syncthreads();
+    for (int i = tid; i < nc; i += kBlock) {
+      o_cxy[2 * i] = (int)(ckey[i] >> 16);
+      o_cxy[2 * i + 1] = (int)(ckey[i] & 0xffffu);
+    }
   } else {
     nk = o_counts[0];
     nc_found = o_counts[1];
@@ -378,6 +526,9 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     //         flags bit2: the north star's variant, the NEAREST centre within thr
     //         (ties to the lower group index)
     const bool nearest = (a.flags & 4) != 0;
+    if constexpr (MODE == 2) {
+      for (int g = tid; g < min(ng, a.max_groups); g += kBlock) o_gn[g] = 0;
+    } else {
     for (int i = tid; i < nk_st; i += kBlock) {
       const double rx = (double)o_root[2 * i], ry = (double)o_root[2 * i + 1];
       int found = -1;
@@ -397,6 +548,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     }
     __syncthreads();
     for (int g = tid; g < min(ng, a.max_groups); g += kBlock) o_gn[g] = gcnt[g];
+    }
   } else {
     // ---- no centre clustering: update_coords_fast (post_process.py:142-153)
     // Greedy over keypoints in order; group ids live in LDS while they fit,
@@ -575,10 +727,16 @@ int decode_batch_launch(const float *heat, const float *offset, const float *err
   const int nwords = (HW + 63) / 64;
 
   const bool fused_mask = nwords <= kFusedMaskWords;
+  // Large images with by-centre grouping (or decode only): keypoint lists and keypoint
+  // assignment on grids over the batch, only the order-dependent centre clustering stays
+  // one workgroup per image.  The no-centre mode clusters the keypoints themselves in
+  // order and keeps the one-workgroup form.
+  const bool split = !fused_mask && (p->by_center_thr >= 0 || (p->flags & 1));
   if (!fused_mask) {
     dim3 g1((HW + kBlock - 1) / kBlock, p->B);
     hipLaunchKernelGGL(decode_mask_kernel, g1, dim3(kBlock), 0, s, heat, HW,
-                       p->W, p->kpt_thr, kmask, nwords, p->flags & 2);
+                       p->W, p->kpt_thr, kmask, nwords, p->flags & 2,
+                       split ? out->counts : nullptr);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
 
@@ -599,7 +757,19 @@ int decode_batch_launch(const float *heat, const float *offset, const float *err
   a.max_groups = p->max_groups;
   a.flags = p->flags;
   a.out = *out;
-  hipLaunchKernelGGL(decode_group_kernel<true>, dim3(p->B), dim3(kBlock), 0, s, a);
+  if (split) {
+    dim3 gg((nwords + kBlock - 1) / kBlock, p->B);
+    hipLaunchKernelGGL(decode_gather_kernel, gg, dim3(kBlock), 0, s, a);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    hipLaunchKernelGGL(decode_group_kernel<2>, dim3(p->B), dim3(kBlock), 0, s, a);
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    if (!(p->flags & 1)) {
+      dim3 ga((p->max_kpts + kBlock - 1) / kBlock, p->B);
+      hipLaunchKernelGGL(decode_assign_kernel, ga, dim3(kBlock), 0, s, a);
+    }
+    return ganet_check_launch();
+  }
+  hipLaunchKernelGGL(decode_group_kernel<0>, dim3(p->B), dim3(kBlock), 0, s, a);
   return ganet_check_launch();
 }
 
@@ -687,7 +857,7 @@ extern "C" int ganet_group_batch(const ganet_decode_params *p,
   a.max_groups = p->max_groups;
   a.flags = p->flags & ~1;
   a.out = *out;
-  hipLaunchKernelGGL(decode_group_kernel<false>, dim3(p->B), dim3(kBlock), 0,
+  hipLaunchKernelGGL(decode_group_kernel<1>, dim3(p->B), dim3(kBlock), 0,
                      static_cast<hipStream_t>(stream), a);
   return ganet_check_launch();
 }

@@ -104,22 +104,25 @@ def test_batch_against_oracle(shape, B, by_center):
             assert np.array_equal(img["center_gid"], cgid)
 
 
-def test_capacity_growth_and_noise_stress():
+@pytest.mark.parametrize("H,W,thr", [(48, 96, 0.3), (96, 160, 0.85)])
+def test_capacity_growth_and_noise_stress(H, W, thr):
     """Uniform-noise heat-maps with a low threshold: thousands of keypoints and
-    hundreds of centres per image; the default capacities overflow and regrow."""
+    hundreds of centres per image; the default capacities overflow and regrow.  48x96 takes
+    the one-workgroup-per-image kernel, 96x160 (more than 8192 pixels) the gridded
+    keypoint gather / assignment kernels around it."""
     rng = np.random.default_rng(5)
-    B, H, W = 6, 48, 96
+    B = 6
     heat = rng.uniform(0, 1, (B, 1, H, W)).astype(np.float32)
     off = rng.normal(0, 2.5, (B, 2, H, W)).astype(np.float32)
     err = rng.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
     for by_center in (4.0, None):
-        res = D.decode_batch(cuda(heat), cuda(off), cuda(err), thr=0.3, root_thr=1,
+        res = D.decode_batch(cuda(heat), cuda(off), cuda(err), thr=thr, root_thr=1,
                              cluster_thr=3.0, cluster_by_center_thr=by_center,
                              max_kpts=64, max_centers=16)
         for b in range(B):
-            c, kxy, al, rt = O.decode(heat[b], off[b], err[b], 0.3, 1.0)
+            c, kxy, al, rt = O.decode(heat[b], off[b], err[b], thr, 1.0)
             gid, means, cgid, ng = O.group_fast(c, rt, 3.0, by_center)
-            assert len(al) > 1000
+            assert len(al) > 500
             check_image_against(res.image(b), c, al, rt, gid, means, ng)
 
 
