@@ -539,11 +539,22 @@ __global__ __launch_bounds__(256) void nhwc_repack_kernel(
   }
 }
 
-// W[Cout][Cin][T] (TS) -> Wp[T][CoutP][Cp] (TD), zero padded.
+// W[Cout][Cin/groups][T] (TS) -> Wp[T][CoutP][Cp] (TD), zero padded.  Convolution groups
+// (deform_conv_cuda.cpp:227-236: one addmm_ per group) become a block-diagonal dense
+// weight: output o of group g = o / (Cout/groups) reads channels [g*Cin/groups,
+// (g+1)*Cin/groups), every other entry of its row is zero, and the kernels stay as they are.
+__device__ __forceinline__ long long grouped_weight_index(int o, int c, int t, int Cout, int Cin,
+                                                          int T, int groups) {
+  const int cig = Cin / groups, cog = Cout / groups;
+  const int cg = c - (o / cog) * cig;
+  if (cg < 0 || cg >= cig) return -1;
+  return ((long long)o * cig + cg) * T + t;
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void pack_weight_kernel(
     const TS *__restrict__ w, TD *__restrict__ wp, int Cout, int Cin, int T,
-    int CoutP, int Cp) {
+    int CoutP, int Cp, int groups) {
   const long long total = (long long)T * CoutP * Cp;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
        i += (long long)gridDim.x * 256) {
@@ -551,7 +562,10 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(
     const int o = (int)((i / Cp) % CoutP);
     const int t = (int)(i / ((long long)Cp * CoutP));
     float v = 0.f;
-    if (o < Cout && c < Cin) v = to_f32(w[((size_t)o * Cin + c) * T + t]);
+    if (o < Cout && c < Cin) {
+      const long long k = grouped_weight_index(o, c, t, Cout, Cin, T, groups);
+      if (k >= 0) v = to_f32(w[k]);
+    }
     wp[i] = from_f32<TD>(v);
   }
 }
@@ -560,7 +574,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(
 // lo = bf16(w - hi)  (cts_gemm_split_kernel, deform_conv_cts.hip)
 __global__ __launch_bounds__(256) void pack_weight_split_kernel(
     const float *__restrict__ w, bf16_t *__restrict__ wp, int Cout, int Cin, int T,
-    int CoutP, int Cp) {
+    int CoutP, int Cp, int groups) {
   const long long total = (long long)T * CoutP * Cp;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
        i += (long long)gridDim.x * 256) {
@@ -568,7 +582,10 @@ __global__ __launch_bounds__(256) void pack_weight_split_kernel(
     const int o = (int)((i / Cp) % CoutP);
     const int t = (int)(i / ((long long)Cp * CoutP));
     float v = 0.f;
-    if (o < Cout && c < Cin) v = w[((size_t)o * Cin + c) * T + t];
+    if (o < Cout && c < Cin) {
+      const long long k = grouped_weight_index(o, c, t, Cout, Cin, T, groups);
+      if (k >= 0) v = w[k];
+    }
     const bf16_t hi = from_f32<bf16_t>(v);
     wp[i] = hi;
     wp[total + i] = from_f32<bf16_t>(v - to_f32(hi));
@@ -612,7 +629,6 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
   pl->Ho = ganet_dcn_out_size(p->H, p->pH, p->dH, p->kH, p->sH);
   pl->Wo = ganet_dcn_out_size(p->W, p->pW, p->dW, p->kW, p->sW);
   if (pl->Ho < 1 || pl->Wo < 1) return GANET_ERR_TOO_SMALL;
-  if (p->groups != 1) return GANET_ERR_UNSUPPORTED;
   if (p->offset_is_points &&
       (p->kH != 1 || p->dW != 1 || p->pW != (p->kW - 1) / 2 || !(p->kW & 1)))
     return GANET_ERR_BAD_SHAPE;
@@ -698,7 +714,7 @@ void launch_pack_weight(const ganet_dcn_params *p, const Plan &pl, const void *w
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL((pack_weight_kernel<TS, TD>), dim3(blocks), dim3(256), 0, s,
                      static_cast<const TS *>(w), static_cast<TD *>(wp), p->Cout,
-                     p->Cin, pl.T, pl.CoutP, pl.Cp);
+                     p->Cin, pl.T, pl.CoutP, pl.Cp, p->groups);
 }
 
 template <typename TA, typename TO, int KCB>
@@ -772,7 +788,7 @@ int pack_weight_dispatch(const ganet_dcn_params *p, const Plan &pl,
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weight_split_kernel, dim3(blocks), dim3(256), 0, s,
                        static_cast<const float *>(weight), static_cast<bf16_t *>(wp),
-                       p->Cout, p->Cin, pl.T, pl.CoutP, pl.Cp);
+                       p->Cout, p->Cin, pl.T, pl.CoutP, pl.Cp, p->groups);
   } else if (p->dtype == GANET_F32 && pl.ta == GANET_F32)
     launch_pack_weight<float, float>(p, pl, weight, wp, s);
   else if (p->dtype == GANET_F32 && pl.ta == GANET_BF16)

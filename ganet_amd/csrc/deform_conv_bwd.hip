@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_bias_kernel(const float *__restri
 
 // ---- layout helpers ------------------------------------------------------------------
 // src[B][C][HW] -> dst[B*HW][Cp] (zero padded channels)
-__global__ __launch_bounds__(256) void bwd_nchw_to_nhwc_kernel(const float *__restrict__ src,
+template <typename TS>
+__global__ __launch_bounds__(256) void bwd_nchw_to_nhwc_kernel(const TS *__restrict__ src,
                                                                float *__restrict__ dst,
                                                                int C, int HW, int Cp) {
   __shared__ float tile[64][65];
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void bwd_nchw_to_nhwc_kernel(const float *__re
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int cc = ty; cc < 64; cc += 4) {
     float v = 0.f;
-    if (c0 + cc < C && p0 + tx < HW) v = src[((size_t)b * C + c0 + cc) * HW + p0 + tx];
+    if (c0 + cc < C && p0 + tx < HW) v = to_f32(src[((size_t)b * C + c0 + cc) * HW + p0 + tx]);
     tile[cc][tx] = v;
   }
   __syncthreads();
@@ -314,8 +315,9 @@ __global__ __launch_bounds__(256) void bwd_nchw_to_nhwc_kernel(const float *__re
 }
 
 // dst[B][C][HW] += src[B*HW][Cp]
+template <typename TD>
 __global__ __launch_bounds__(256) void bwd_add_nhwc_to_nchw_kernel(const float *__restrict__ src,
-                                                                   float *__restrict__ dst,
+                                                                   TD *__restrict__ dst,
                                                                    int C, int HW, int Cp) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z;
@@ -328,11 +330,15 @@ __global__ __launch_bounds__(256) void bwd_add_nhwc_to_nchw_kernel(const float *
   }
   __syncthreads();
   for (int cc = ty; cc < 64; cc += 4)
-    if (c0 + cc < C && p0 + tx < HW) dst[((size_t)b * C + c0 + cc) * HW + p0 + tx] += tile[tx][cc];
+    if (c0 + cc < C && p0 + tx < HW) {
+      TD *d = dst + ((size_t)b * C + c0 + cc) * HW + p0 + tx;
+      *d = from_f32<TD>(to_f32(*d) + tile[tx][cc]);
+    }
 }
 
 // src[N][C] -> dst[N][Cp] (zero padded); and dst[N][C] += src[N][Cp]
-__global__ __launch_bounds__(256) void bwd_pad_rows_kernel(const float *__restrict__ src,
+template <typename TS>
+__global__ __launch_bounds__(256) void bwd_pad_rows_kernel(const TS *__restrict__ src,
                                                            float *__restrict__ dst, long long n,
                                                            int C, int Cp) {
   const long long total = n * Cp;
@@ -340,43 +346,54 @@ __global__ __launch_bounds__(256) void bwd_pad_rows_kernel(const float *__restri
        k += (long long)gridDim.x * 256) {
     const long long r = k / Cp;
     const int cc = (int)(k - r * Cp);
-    dst[k] = cc < C ? src[r * C + cc] : 0.f;
+    dst[k] = cc < C ? to_f32(src[r * C + cc]) : 0.f;
   }
 }
+template <typename TD>
 __global__ __launch_bounds__(256) void bwd_add_rows_kernel(const float *__restrict__ src,
-                                                           float *__restrict__ dst, long long n,
+                                                           TD *__restrict__ dst, long long n,
                                                            int C, int Cp) {
   const long long total = n * C;
   for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
        k += (long long)gridDim.x * 256) {
     const long long r = k / C;
     const int cc = (int)(k - r * C);
-    dst[k] += src[r * Cp + cc];
+    dst[k] = from_f32<TD>(to_f32(dst[k]) + src[r * Cp + cc]);
   }
 }
 
-// W[Cout][Cin][T] -> wp[T][Cout][Cp]; and gw[Cout][Cin][T] += gwp[T][Cout][Cp]
-__global__ __launch_bounds__(256) void bwd_pack_weight_kernel(const float *__restrict__ w,
+// W[Cout][Cin/groups][T] -> wp[T][Cout][Cp]; and gw[Cout][Cin/groups][T] += gwp[T][Cout][Cp].
+// Convolution groups (deform_conv_cuda.cpp:227-236, :439-470) are a block-diagonal dense
+// weight here, as in the forward: entries outside a row's group are packed as zeros, and
+// the dense weight gradient's entries outside the groups are simply not read back.
+template <typename TS>
+__global__ __launch_bounds__(256) void bwd_pack_weight_kernel(const TS *__restrict__ w,
                                                               float *__restrict__ wp, int Cout,
-                                                              int Cin, int T, int Cp) {
+                                                              int Cin, int T, int Cp, int groups) {
+  const int cig = Cin / groups, cog = Cout / groups;
   const long long total = (long long)T * Cout * Cp;
   for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
        k += (long long)gridDim.x * 256) {
     const int cc = (int)(k % Cp);
     const int o = (int)((k / Cp) % Cout);
     const int t = (int)(k / ((long long)Cp * Cout));
-    wp[k] = cc < Cin ? w[((size_t)o * Cin + cc) * T + t] : 0.f;
+    const int cg = cc - (o / cog) * cig;
+    wp[k] = (cc < Cin && cg >= 0 && cg < cig) ? to_f32(w[((size_t)o * cig + cg) * T + t]) : 0.f;
   }
 }
+template <typename TD>
 __global__ __launch_bounds__(256) void bwd_unpack_add_weight_kernel(
-    const float *__restrict__ gwp, float *__restrict__ gw, int Cout, int Cin, int T, int Cp) {
-  const long long total = (long long)Cout * Cin * T;
+    const float *__restrict__ gwp, TD *__restrict__ gw, int Cout, int Cin, int T, int Cp,
+    int groups) {
+  const int cig = Cin / groups, cog = Cout / groups;
+  const long long total = (long long)Cout * cig * T;
   for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
        k += (long long)gridDim.x * 256) {
     const int t = (int)(k % T);
-    const int cc = (int)((k / T) % Cin);
-    const int o = (int)(k / ((long long)T * Cin));
-    gw[k] += gwp[((size_t)t * Cout + o) * Cp + cc];
+    const int cg = (int)((k / T) % cig);
+    const int o = (int)(k / ((long long)T * cig));
+    const int cc = (o / cog) * cig + cg;
+    gw[k] = from_f32<TD>(to_f32(gw[k]) + gwp[((size_t)t * Cout + o) * Cp + cc]);
   }
 }
 
@@ -1028,9 +1045,10 @@ struct BwdPlan {
   bool commuted;
   int nb;                 // images per chunk
   size_t y_bytes, gy_bytes, gxc_bytes, wqt_bytes, wsp_bytes, geo_bytes;
+  size_t gb_bytes;   // float32 bias gradient of a 16-bit call
   size_t total() const {
     return xh_bytes + gxh_bytes + go_bytes + wp_bytes + gwp_bytes + y_bytes + gy_bytes +
-           gxc_bytes + wqt_bytes + wsp_bytes + geo_bytes;
+           gxc_bytes + wqt_bytes + wsp_bytes + geo_bytes + gb_bytes;
   }
 };
 
@@ -1044,8 +1062,12 @@ int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
   if (p->groups <= 0 || p->deformable_groups <= 0) return GANET_ERR_BAD_SHAPE;
   if (p->Cin % p->groups || p->Cout % p->groups || p->Cin % p->deformable_groups)
     return GANET_ERR_BAD_SHAPE;
-  if (p->dtype != GANET_F32) return GANET_ERR_UNSUPPORTED;   // training runs in float32
-  if (p->groups != 1) return GANET_ERR_UNSUPPORTED;
+  if (p->dtype != GANET_F32 && p->dtype != GANET_BF16 && p->dtype != GANET_F16)
+    return GANET_ERR_BAD_SHAPE;
+  // 16-bit tensors (the reference dispatches half here too, deform_conv_cuda_kernel.cu:259 and
+  // the col2im launchers): x, grad_out and the weights are widened to float32 copies in the
+  // workspace, the gradients are formed in float32 and rounded once on the way out
+  const bool io16 = p->dtype != GANET_F32;
   if (p->offset_is_points || p->fuse_relu || p->weight_is_packed) return GANET_ERR_UNSUPPORTED;
   pl->Ho = ganet_dcn_out_size(p->H, p->pH, p->dH, p->kH, p->sH);
   pl->Wo = ganet_dcn_out_size(p->W, p->pW, p->dW, p->kW, p->sW);
@@ -1059,8 +1081,9 @@ int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
   const size_t npix_out = (size_t)p->B * pl->Ho * pl->Wo;
   if (npix_in * pl->Cp >= 0x7fffffffull || npix_out >= 0x7fffffffull)
     return GANET_ERR_UNSUPPORTED;  // 32-bit row indices in the sample table
-  pl->copy_x = p->x_layout != GANET_NHWC || pl->Cp != p->Cin;
-  pl->copy_go = p->out_layout != GANET_NHWC;
+  pl->copy_x = p->x_layout != GANET_NHWC || pl->Cp != p->Cin || io16;
+  pl->copy_go = p->out_layout != GANET_NHWC || io16;
+  pl->gb_bytes = io16 ? ganet_align_up((size_t)p->Cout * 4, 256) : 0;
   pl->xh_bytes = pl->copy_x ? ganet_align_up(npix_in * pl->Cp * 4, 256) : 0;
   pl->gxh_bytes = pl->xh_bytes;
   pl->go_bytes = pl->copy_go ? ganet_align_up(npix_out * p->Cout * 4, 256) : 0;
@@ -1115,6 +1138,21 @@ int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
 
 using namespace ganet_dcn;
 
+// runs `...` with TIO = the element type of the caller's tensors
+#define GANET_IO_DISPATCH(dt, ...)      \
+  do {                                  \
+    if ((dt) == GANET_F32) {            \
+      typedef float TIO;                \
+      __VA_ARGS__;                      \
+    } else if ((dt) == GANET_BF16) {    \
+      typedef bf16_t TIO;               \
+      __VA_ARGS__;                      \
+    } else {                            \
+      typedef f16_t TIO;                \
+      __VA_ARGS__;                      \
+    }                                   \
+  } while (0)
+
 extern "C" size_t ganet_deform_conv_backward_workspace_bytes(const ganet_dcn_params *p) {
   BwdPlan pl;
   if (make_bwd_plan(p, &pl) != GANET_OK) return 0;
@@ -1148,8 +1186,9 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
 
   const int HW = p->H * p->W, HWo = pl.Ho * pl.Wo, T = pl.T;
   const long long npix_in = (long long)p->B * HW, P = (long long)p->B * HWo;
-  const float *xf = static_cast<const float *>(x);
+  const float *xf = static_cast<const float *>(x);          // float32 calls only where used as is
   const float *gof = static_cast<const float *>(grad_out);
+  const int dt = p->dtype;
   auto blocks_for = [](long long n) {
     long long b = (n + 255) / 256;
     return (unsigned)(b > 65535 ? 65535 : (b < 1 ? 1 : b));
@@ -1158,18 +1197,29 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
   // channel-last views of x and grad_out
   if (pl.copy_x) {
     if (p->x_layout == GANET_NHWC) {
-      hipLaunchKernelGGL(bwd_pad_rows_kernel, dim3(blocks_for(npix_in * pl.Cp)), dim3(256), 0, s,
-                         xf, xh, npix_in, p->Cin, pl.Cp);
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_pad_rows_kernel<TIO>,
+                                               dim3(blocks_for(npix_in * pl.Cp)), dim3(256), 0, s,
+                                               static_cast<const TIO *>(x), xh, npix_in, p->Cin,
+                                               pl.Cp));
     } else {
       dim3 grid((HW + 63) / 64, (pl.Cp + 63) / 64, p->B);
-      hipLaunchKernelGGL(bwd_nchw_to_nhwc_kernel, grid, dim3(256), 0, s, xf, xh, p->Cin, HW, pl.Cp);
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_nchw_to_nhwc_kernel<TIO>, grid, dim3(256), 0, s,
+                                               static_cast<const TIO *>(x), xh, p->Cin, HW, pl.Cp));
     }
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
   if (pl.copy_go) {
-    dim3 grid((HWo + 63) / 64, (p->Cout + 63) / 64, p->B);
-    hipLaunchKernelGGL(bwd_nchw_to_nhwc_kernel, grid, dim3(256), 0, s, gof, goh, p->Cout, HWo,
-                       p->Cout);
+    if (p->out_layout == GANET_NHWC) {   // 16-bit channel-last grad_out: widened only
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_pad_rows_kernel<TIO>,
+                                               dim3(blocks_for(P * p->Cout)), dim3(256), 0, s,
+                                               static_cast<const TIO *>(grad_out), goh, P, p->Cout,
+                                               p->Cout));
+    } else {
+      dim3 grid((HWo + 63) / 64, (p->Cout + 63) / 64, p->B);
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_nchw_to_nhwc_kernel<TIO>, grid, dim3(256), 0, s,
+                                               static_cast<const TIO *>(grad_out), goh, p->Cout,
+                                               HWo, p->Cout));
+    }
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
 
@@ -1213,8 +1263,10 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
     unsigned char *geo = cw + pl.y_bytes + pl.gy_bytes + pl.gxc_bytes + pl.wqt_bytes + pl.wsp_bytes;
     const int N = T * p->Cout;
     if (need_in) {
-      hipLaunchKernelGGL(bwd_pack_weight_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256),
-                         0, s, static_cast<const float *>(weight), wp, p->Cout, p->Cin, T, pl.Cp);
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_pack_weight_kernel<TIO>,
+                                               dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
+                                               s, static_cast<const TIO *>(weight), wp, p->Cout,
+                                               p->Cin, T, pl.Cp, p->groups));
       hipLaunchKernelGGL(bwd_transpose_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
                          s, wp, wqt, N, pl.Cp);
       hipLaunchKernelGGL(bwd_split_rows_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
@@ -1289,7 +1341,8 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
                            dim3(CS_WAVES * 64), 0, s, c);
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
       }
-      if (need_in && pl.Cp <= 256 && p->x_layout == GANET_NHWC && pl.Cp == p->Cin) {
+      if (need_in && pl.Cp <= 256 && p->x_layout == GANET_NHWC && pl.Cp == p->Cin &&
+          dt == GANET_F32) {
         // grad_x += grad_Y * Wq straight into the caller's channel-last tensor (three bf16
         // passes, K-outer kernel: grad_Y is read once)
         float *gx = static_cast<float *>(grad_x) + (size_t)img0 * HW * p->Cin;
@@ -1302,14 +1355,17 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
                                                       pl.Cp, pl.Cp, 0, s)
                             : cts_gemm_f32(gyb, wqt, gxc, M, N, pl.Cp, s);
         if (rc2 != GANET_OK) return rc2;
-        float *gx = static_cast<float *>(grad_x);
         if (p->x_layout == GANET_NHWC) {
-          hipLaunchKernelGGL(bwd_add_rows_kernel, dim3(blocks_for(M * p->Cin)), dim3(256), 0, s, gxc,
-                             gx + (size_t)img0 * HW * p->Cin, M, p->Cin, pl.Cp);
+          GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(
+                                    bwd_add_rows_kernel<TIO>, dim3(blocks_for(M * p->Cin)), dim3(256),
+                                    0, s, gxc, static_cast<TIO *>(grad_x) + (size_t)img0 * HW * p->Cin,
+                                    M, p->Cin, pl.Cp));
         } else {
           dim3 grid((HW + 63) / 64, (pl.Cp + 63) / 64, nimg);
-          hipLaunchKernelGGL(bwd_add_nhwc_to_nchw_kernel, grid, dim3(256), 0, s, gxc,
-                             gx + (size_t)img0 * p->Cin * HW, p->Cin, HW, pl.Cp);
+          GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(
+                                    bwd_add_nhwc_to_nchw_kernel<TIO>, grid, dim3(256), 0, s, gxc,
+                                    static_cast<TIO *>(grad_x) + (size_t)img0 * p->Cin * HW, p->Cin,
+                                    HW, pl.Cp));
         }
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
       }
@@ -1327,16 +1383,19 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
       }
     }
     if (grad_weight) {
-      hipLaunchKernelGGL(bwd_unpack_add_weight_kernel,
-                         dim3(blocks_for((long long)p->Cout * p->Cin * T)), dim3(256), 0, s, gwp,
-                         static_cast<float *>(grad_weight), p->Cout, p->Cin, T, pl.Cp);
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(
+                                bwd_unpack_add_weight_kernel<TIO>,
+                                dim3(blocks_for((long long)p->Cout * p->Cin * T)), dim3(256), 0, s,
+                                gwp, static_cast<TIO *>(grad_weight), p->Cout, p->Cin, T, pl.Cp,
+                                p->groups));
       if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
     }
   } else {
   if (need_in) {
-    hipLaunchKernelGGL(bwd_pack_weight_kernel, dim3(blocks_for((long long)T * p->Cout * pl.Cp)),
-                       dim3(256), 0, s, static_cast<const float *>(weight), wp, p->Cout, p->Cin,
-                       T, pl.Cp);
+    GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_pack_weight_kernel<TIO>,
+                                             dim3(blocks_for((long long)T * p->Cout * pl.Cp)),
+                                             dim3(256), 0, s, static_cast<const TIO *>(weight), wp,
+                                             p->Cout, p->Cin, T, pl.Cp, p->groups));
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
     if (pl.copy_x && hipMemsetAsync(gxh, 0, pl.gxh_bytes, s) != hipSuccess) return GANET_ERR_HIP;
     const size_t off_elems = (size_t)p->B * a.dg * 2 * T * HWo;
@@ -1348,14 +1407,16 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
                        dim3(BW_WAVES * 64), 0, s, a);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
     if (pl.copy_x) {
-      float *gx = static_cast<float *>(grad_x);
       if (p->x_layout == GANET_NHWC) {
-        hipLaunchKernelGGL(bwd_add_rows_kernel, dim3(blocks_for(npix_in * p->Cin)), dim3(256), 0,
-                           s, gxh, gx, npix_in, p->Cin, pl.Cp);
+        GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_add_rows_kernel<TIO>,
+                                                 dim3(blocks_for(npix_in * p->Cin)), dim3(256), 0, s,
+                                                 gxh, static_cast<TIO *>(grad_x), npix_in, p->Cin,
+                                                 pl.Cp));
       } else {
         dim3 grid((HW + 63) / 64, (pl.Cp + 63) / 64, p->B);
-        hipLaunchKernelGGL(bwd_add_nhwc_to_nchw_kernel, grid, dim3(256), 0, s, gxh, gx, p->Cin,
-                           HW, pl.Cp);
+        GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_add_nhwc_to_nchw_kernel<TIO>, grid, dim3(256),
+                                                 0, s, gxh, static_cast<TIO *>(grad_x), p->Cin, HW,
+                                                 pl.Cp));
       }
       if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
     }
@@ -1370,17 +1431,26 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
     dim3 grid((unsigned)(T * (pl.Cp / 32)), (unsigned)split);
     hipLaunchKernelGGL(dcn_bwd_weight_kernel, grid, dim3(BW_WAVES * 64), 0, s, a);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
-    hipLaunchKernelGGL(bwd_unpack_add_weight_kernel,
-                       dim3(blocks_for((long long)p->Cout * p->Cin * T)), dim3(256), 0, s, gwp,
-                       static_cast<float *>(grad_weight), p->Cout, p->Cin, T, pl.Cp);
+    GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(
+                              bwd_unpack_add_weight_kernel<TIO>,
+                              dim3(blocks_for((long long)p->Cout * p->Cin * T)), dim3(256), 0, s, gwp,
+                              static_cast<TIO *>(grad_weight), p->Cout, p->Cin, T, pl.Cp, p->groups));
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
   }  // direct form
   if (grad_bias) {
     long long nb = (P + 1023) / 1024;
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3((unsigned)nb), dim3(256), 0, s, a.go,
-                       static_cast<float *>(grad_bias), P, p->Cout);
+    float *gb = static_cast<float *>(grad_bias);
+    if (dt != GANET_F32) {   // summed in float32 scratch, added to the 16-bit tensor afterwards
+      gb = reinterpret_cast<float *>(ws + need - pl.gb_bytes);
+      if (hipMemsetAsync(gb, 0, pl.gb_bytes, s) != hipSuccess) return GANET_ERR_HIP;
+    }
+    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3((unsigned)nb), dim3(256), 0, s, a.go, gb, P,
+                       p->Cout);
+    if (dt != GANET_F32)
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_add_rows_kernel<TIO>, dim3(1), dim3(256), 0, s, gb,
+                                               static_cast<TIO *>(grad_bias), 1ll, p->Cout, p->Cout));
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
   return GANET_OK;

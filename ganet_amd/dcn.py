@@ -11,7 +11,7 @@ Only names, signatures, attribute names, state-dict keys and exception types/mes
 are the reference's (they are the drop-in contract); the bodies are written against the
 C-ABI.  Forward and backward run the HIP kernels (csrc/deform_conv*.hip); there is no
 eager / CPU fallback: CPU tensors raise NotImplementedError like the reference.  The backward
-takes float32 tensors only (the reference also dispatches half there).
+takes float32, bfloat16 and float16 tensors (16-bit ones are widened inside the library).
 'DCN' / 'DCNv2' are registered with mmcv's CONV_LAYERS only on request:
 register_with_mmcv().
 """
@@ -198,20 +198,22 @@ def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
     2 commuted (Cout-wide rows through the per-tap products; where it applies)."""
     if not grad_output.is_cuda or not input.is_cuda:
         raise NotImplementedError
-    if input.dtype != torch.float32:
-        raise NotImplementedError(
-            "ganet_amd: deform_conv backward is built for float32 only (got %s)" % input.dtype)
+    if input.dtype not in _DTYPES:
+        raise TypeError("deform_conv: unsupported dtype %s" % input.dtype)
     L = _lib.lib()
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     nhwc = _is_channels_last(input)
     if not nhwc:
         input = input.contiguous()
-    weight = weight.contiguous().float()
+    # x, weight, grad_output and the gradients of x / weight / bias share the tensors' dtype
+    # (16-bit ones are widened inside the library, gradients formed in float32 and rounded
+    # once); offsets, masks and their gradients are float32 as in the forward
+    weight = weight.contiguous().to(input.dtype)
     offset = offset.contiguous().float()
     if mask is not None:
         mask = mask.contiguous().float()
     go_nhwc = _is_channels_last(grad_output)
-    grad_output = grad_output.float()
+    grad_output = grad_output.to(input.dtype)
     if not go_nhwc:
         grad_output = grad_output.contiguous()
     B, Cin, H, W = input.shape
@@ -223,7 +225,7 @@ def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
     p.pH, p.pW = padding
     p.dH, p.dW = dilation
     p.groups, p.deformable_groups = groups, deformable_groups
-    p.dtype = _lib.GANET_F32
+    p.dtype = _DTYPES[input.dtype]
     p.x_layout = _lib.GANET_NHWC if nhwc else _lib.GANET_NCHW
     p.out_layout = _lib.GANET_NHWC if go_nhwc else _lib.GANET_NCHW
     p.algo = algo
@@ -236,7 +238,7 @@ def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
     if need_weight:
         grad_weight = torch.zeros_like(weight)
     if need_bias:
-        grad_bias = torch.zeros(Cout, dtype=torch.float32, device=input.device)
+        grad_bias = torch.zeros(Cout, dtype=input.dtype, device=input.device)
 
     def ptr(t):
         return t.data_ptr() if t is not None else None
@@ -300,6 +302,8 @@ class DeformConvFunction(Function):
             input, offset, weight, grad_output, ctx.stride, ctx.padding, ctx.dilation,
             ctx.groups, ctx.deformable_groups, need_input=want[0] or want[1],
             need_weight=want[2])
+        if g_off is not None:
+            g_off = g_off.to(offset.dtype)
         return (g_in, g_off, g_w) + (None,) * 6
 
     @staticmethod
@@ -348,6 +352,7 @@ class ModulatedDeformConvFunction(Function):
             _pair(ctx.dilation), ctx.groups, ctx.deformable_groups, mask=mask,
             need_input=True, need_weight=True, need_bias=ctx.with_bias)
         g_in, g_off, g_mask, g_w, g_b = grads
+        g_off, g_mask = g_off.to(offset.dtype), g_mask.to(mask.dtype)
         return (g_in, g_off, g_mask, g_w, g_b if ctx.with_bias else None) + (None,) * 5
 
     @staticmethod

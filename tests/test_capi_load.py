@@ -71,7 +71,7 @@ def test_dcn_workspace_and_validation_without_gpu():
                      (dict(sW=0), _lib.GANET_ERR_BAD_SHAPE),
                      (dict(Cin=63, deformable_groups=2), _lib.GANET_ERR_BAD_SHAPE),
                      (dict(W=2, pW=0), _lib.GANET_ERR_TOO_SMALL),
-                     (dict(groups=2), _lib.GANET_ERR_UNSUPPORTED),
+                     (dict(groups=3), _lib.GANET_ERR_BAD_SHAPE),      # 256 % 3 != 0
                      (dict(dtype=7), _lib.GANET_ERR_BAD_SHAPE)]:
         q = _dcn_params(**kw)
         rc = L.ganet_deform_conv_forward(fake, fake, None, fake, None, fake,

@@ -242,16 +242,93 @@ def test_autograd_through_the_modules():
 
 def test_backward_rejects_what_it_does_not_build():
     dev = torch.device("cuda", 0)
-    x = torch.zeros(1, 32, 6, 6, device=dev, dtype=torch.bfloat16)
-    with pytest.raises(NotImplementedError):
-        dcn.deform_conv_backward(x, torch.zeros(1, 18, 6, 6, device=dev),
-                                 torch.zeros(8, 32, 3, 3, device=dev, dtype=torch.bfloat16),
-                                 torch.zeros(1, 8, 6, 6, device=dev, dtype=torch.bfloat16),
-                                 (1, 1), (1, 1), (1, 1))
-    # conv groups > 1 and deformable groups of 16 channels: status UNSUPPORTED
+    # deformable groups of 16 channels (tiles of 32 would straddle them): status UNSUPPORTED
     x = torch.zeros(1, 32, 6, 6, device=dev)
     with pytest.raises(_lib.GanetError):
         dcn.deform_conv_backward(x, torch.zeros(1, 36, 6, 6, device=dev),
                                  torch.zeros(8, 32, 3, 3, device=dev),
                                  torch.zeros(1, 8, 6, 6, device=dev), (1, 1), (1, 1), (1, 1),
                                  1, 2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5]])
+@pytest.mark.parametrize("modulated,channels_last", [(False, True), (True, False)])
+def test_backward_16bit(dtype, case, modulated, channels_last):
+    """bf16 / f16 tensors (the reference dispatches half in its backward,
+    deform_conv_cuda_kernel.cu:259): x, weight and grad_out are widened inside the library, so
+    against the oracle on the SAME rounded values the only differences are float32 summation
+    order and one rounding of each gradient to 16 bits: 1e-2 of the gradient's scale (the
+    north star's 16-bit tolerance), grad_offset / grad_mask stay float32 (1e-4)."""
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 8, modulated)
+    dev = torch.device("cuda", 0)
+    tx, tw, tgo = (torch.from_numpy(a).to(dev).to(dtype) for a in (x, w, go))
+    ref = O.deform_conv_backward(tx.float().cpu().numpy(), off, tw.float().cpu().numpy(),
+                                 tgo.float().cpu().numpy(), st, pad, dil, 1, dg, mask=mask)
+    toff = torch.from_numpy(off).to(dev)
+    tm = torch.from_numpy(mask).to(dev) if modulated else None
+    if channels_last:
+        tx = tx.contiguous(memory_format=torch.channels_last)
+        tgo = tgo.contiguous(memory_format=torch.channels_last)
+    gi, goff, gm, gw, gb = dcn.deform_conv_backward(
+        tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm, need_bias=modulated)
+    assert gi.dtype == dtype and gw.dtype == dtype and goff.dtype == torch.float32
+
+    def rel(got, want):
+        got = got.detach().float().cpu().numpy()
+        return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+    assert rel(gi, ref["grad_x"]) <= 1e-2
+    assert rel(gw, ref["grad_weight"]) <= 1e-2
+    assert rel(goff, ref["grad_offset"]) <= 1e-4
+    if modulated:
+        assert rel(gm, ref["grad_mask"]) <= 1e-4
+        assert rel(gb, ref["grad_bias"]) <= 1e-2
+
+
+GROUPED = [
+    # B, Cin, H, W, Cout, kH, kW, stride, pad, dil, dg, groups
+    (2, 64, 9, 13, 32, 3, 3, (1, 1), (1, 1), (1, 1), 1, 2),
+    (1, 128, 8, 10, 64, 1, 7, (1, 1), (0, 3), (1, 1), 1, 4),
+    (2, 64, 11, 14, 24, 3, 3, (2, 2), (1, 1), (1, 1), 2, 2),   # with 2 deformable groups
+    (2, 256, 8, 12, 64, 1, 7, (1, 1), (0, 3), (1, 1), 1, 2),   # the commuted forms' shape
+]
+
+
+@pytest.mark.parametrize("case", GROUPED)
+@pytest.mark.parametrize("modulated", [False, True])
+def test_conv_groups_forward_and_backward(case, modulated):
+    """Convolution groups > 1 (one addmm_ per group in the reference,
+    deform_conv_cuda.cpp:227-236, :439-470): weight [Cout, Cin/groups, kH, kW]; forward and
+    all gradients against the oracle, float32."""
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg, g = case
+    x, off, _, mask, go = make(case[:-1], 13, modulated)
+    rng = np.random.default_rng(2)
+    w = (rng.standard_normal((Cout, Cin // g, kH, kW)) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32) if modulated else None
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo = (torch.from_numpy(a).to(dev) for a in (x, off, w, go))
+    tm = torch.from_numpy(mask).to(dev) if modulated else None
+    fref = O.deform_conv_forward(x, off, w, st, pad, dil, g, dg, mask=mask, bias=bias)
+    for algo in (0, 1):
+        out = dcn.deform_conv_forward(tx, toff, tw, st, pad, dil, g, dg, mask=tm,
+                                      bias=None if bias is None else torch.from_numpy(bias).to(dev),
+                                      algo=algo)
+        close(out, fref, "forward algo %d" % algo)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, g, dg, mask=mask)
+    gi, goff, gm, gw, gb = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, g, dg,
+                                                    mask=tm, need_bias=modulated)
+    assert tuple(gw.shape) == (Cout, Cin // g, kH, kW)
+    close(gi, ref["grad_x"], "grad_x")
+    close(goff, ref["grad_offset"], "grad_offset")
+    close(gw, ref["grad_weight"], "grad_weight")
+    if modulated:
+        close(gm, ref["grad_mask"], "grad_mask")
+        close(gb, ref["grad_bias"], "grad_bias")
+    # and through the module API
+    m = dcn.DeformConv(Cin, Cout, (kH, kW), st, pad, dil, groups=g, deformable_groups=dg).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(tw)
+    if not modulated:
+        close(m(tx, toff), fref, "DeformConv(groups=%d)" % g)
