@@ -11,7 +11,11 @@
  * synchronises with the host, and enqueues only on the stream it is given.
  * All entry points are re-entrant; the only state the library keeps between calls
  * is the per-GPU address of the static scratch array of ganet_decode_batch_noalloc.
+ * A few measurement knobs are read from the environment on every call (INTEGRATION.md,
+ * "Build, limits"): a workspace query and the call it sizes must see the same values.
  * Call them from one host thread per GPU with that GPU current.
+ * Forward AND backward of the operators are here (ganet_deform_conv_backward), plus
+ * host-only routines that turn decoded records into the reference's result formats.
  *
  * Citations are file:line in the reference tree (Wolfwjs/GANet).
  */
@@ -64,8 +68,9 @@ int ganet_abi_version(void);
  * It is called from DeformConvFunction.forward (mmdet/ops/dcn/deform_conv.py:52-57).
  *
  * There is no im2col buffer and no im2col_step chunking: sampling and the
- * contraction are one fused kernel, or (16-bit arithmetic, Cout < Cin) the
- * commuted pair "per-tap GEMM, then sampling" - see `algo` below.
+ * contraction are one fused kernel, or (2*Cout <= Cin; 16-bit arithmetic, or float32
+ * tensors contracted as three bf16 passes) the commuted pair "per-tap GEMM, then
+ * sampling" - see `algo` below.
  * ---------------------------------------------------------------------- */
 typedef struct {
   int32_t B, Cin, H, W, Cout;
@@ -210,7 +215,13 @@ typedef struct {
   float root_thr;       /* offset_y < root_thr, compared in float32 */
   double cluster_thr;   /* PostProcessor.cluster_thr: used when by_center_thr < 0
                            (update_coords_fast, post_process.py:142-153) */
-  double by_center_thr; /* PostProcessor.cluster_by_center_thr; < 0 means None */
+  double by_center_thr; /* PostProcessor.cluster_by_center_thr; < 0 means None.  Cost
+                           note for None: update_coords_fast clusters the KEYPOINTS
+                           greedily in order (post_process.py:142-153), which is serial
+                           per image here too: nk^2/64 distance evaluations on one
+                           wavefront - milliseconds from ~10^4 keypoints per image
+                           (a negative kpt_thr selects every pixel).  By-centre mode,
+                           which every shipped config uses, has no such term. */
   int32_t max_kpts;     /* capacity of the per-image keypoint arrays */
   int32_t max_centers;  /* capacity of the per-image centre arrays (<= 2048) */
   int32_t max_groups;   /* capacity of the per-image group arrays */
