@@ -84,6 +84,12 @@ def lib():
             raise RuntimeError(
                 "ganet_amd: %s is missing - build it with `python -m ganet_amd.build` "
                 "(there is no CPU or eager fallback)" % LIB_PATH)
+        # torch carries its own libamdhip64; it has to be in the process BEFORE this
+        # library is, so that both bind to ONE HIP runtime.  Loaded the other way round
+        # (this library first, against /opt/rocm's runtime, torch's afterwards) the
+        # streams and pointers torch hands over belong to a different runtime and every
+        # launch fails with GANET_ERR_HIP.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.ganet_status_string.restype = ctypes.c_char_p
         L.ganet_status_string.argtypes = [ctypes.c_int]

@@ -36,6 +36,12 @@ def build_lib(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(ROOT, "include", "ganet_hip.h"), os.path.join(CSRC, "dcn_device.h"),
                os.path.join(CSRC, "common.h")]
+    srcs = [os.path.join(CSRC, src) for src in SOURCES]
+    if not force and not extra and os.path.exists(LIB) and \
+            not any(_newer(f, LIB) for f in srcs + headers):
+        # the library is newer than everything it is built from: on the GPU box the
+        # objects do not travel (.gpurunignore) but the library does, and is used as it is
+        return LIB
     objs, relink = [], force or not os.path.exists(LIB)
     for src in SOURCES:
         s = os.path.join(CSRC, src)

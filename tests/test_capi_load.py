@@ -25,11 +25,29 @@ def test_exports_match_header():
         assert hasattr(L, n), "missing export %s" % n
 
 
+def test_one_hip_runtime_in_the_process():
+    """The binding loaded BEFORE torch must still end up on torch's HIP runtime: with two
+    libamdhip64 in one process every launch on a torch stream fails (GANET_ERR_HIP), which
+    is what build() followed by smoke() in one process used to do."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from ganet_amd import _lib\n"
+        "_lib.lib()\n"
+        "import torch\n"
+        "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "print(len(libs), libs)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == "1", out.stdout
+
+
 def test_status_strings_and_version():
     L = _lib.lib()
     assert L.ganet_abi_version() == 1
     assert _lib.status_string(0) == "ok"
-    for code in range(-6, 0):
+    for code in range(-7, 0):
         assert _lib.status_string(code) != "unknown status"
     assert _lib.status_string(-99) == "unknown status"
 
