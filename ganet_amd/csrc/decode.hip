@@ -44,24 +44,36 @@ constexpr int kFusedMaskWords = 128;  // images up to 8192 pixels: bitmap formed
 // ATen's pool starts at -inf and takes v when (v > max) || isnan(v).
 // rows3: the north star's 3x3 window (max_pool2d(heat,(3,3),1,(1,1)), walked row-major
 // like ATen); the reference always runs 1x3.  `img` is the image's first row.
+// flags bit3: the plane holds LOGITS and every value read goes through
+//   hm = torch.clamp(hm.sigmoid(), min=1e-4, max=1 - 1e-4)      ganet_head.py:291
+// first: 1 / (1 + exp(-v)) in float32 as ATen's GPU sigmoid forms it, then clamp's
+// min/max order with NaN kept.
+__device__ __forceinline__ float heat_prob(float v) {
+  const float s = 1.0f / (1.0f + expf(-v));
+  const float lo = 1e-4f, hi = (float)(1 - 1e-4);
+  return s != s ? s : fminf(fmaxf(s, lo), hi);
+}
+
+template <bool LOGITS>
 __device__ __forceinline__ float heat_nms(const float *__restrict__ img, int H, int W,
                                           int y, int x, bool rows3) {
-  const float h = img[y * W + x];
+  auto rd = [](float v) { return LOGITS ? heat_prob(v) : v; };
+  const float h = rd(img[y * W + x]);
   float m = -INFINITY;
   const int y0 = rows3 && y > 0 ? y - 1 : y;
   const int y1 = rows3 && y < H - 1 ? y + 1 : y;
   for (int yy = y0; yy <= y1; ++yy) {
     const float *row = img + yy * W;
     if (x > 0) {
-      const float v = row[x - 1];
+      const float v = rd(row[x - 1]);
       if (v > m || v != v) m = v;
     }
     {
-      const float v = row[x];
+      const float v = rd(row[x]);
       if (v > m || v != v) m = v;
     }
     if (x < W - 1) {
-      const float v = row[x + 1];
+      const float v = rd(row[x + 1]);
       if (v > m || v != v) m = v;
     }
   }
@@ -71,7 +83,7 @@ __device__ __forceinline__ float heat_nms(const float *__restrict__ img, int H, 
 
 __global__ __launch_bounds__(kBlock) void decode_mask_kernel(
     const float *__restrict__ heat, int HW, int W, float thr,
-    unsigned long long *__restrict__ kmask, int nwords, int rows3,
+    unsigned long long *__restrict__ kmask, int nwords, int rows3, int logits,
     int32_t *__restrict__ counts) {
   const int b = blockIdx.y;
   const int idx = blockIdx.x * kBlock + threadIdx.x;
@@ -82,7 +94,9 @@ __global__ __launch_bounds__(kBlock) void decode_mask_kernel(
   if (idx < HW) {
     const int y = idx / W;
     const int x = idx - y * W;
-    is_kpt = heat_nms(heat + (size_t)b * HW, HW / W, W, y, x, rows3 != 0) > thr;
+    const float *img = heat + (size_t)b * HW;
+    is_kpt = (logits ? heat_nms<true>(img, HW / W, W, y, x, rows3 != 0)
+                     : heat_nms<false>(img, HW / W, W, y, x, rows3 != 0)) > thr;
   }
   const unsigned long long m = __ballot(is_kpt);
   const int word = idx >> 6;
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
   const bool fused_mask = kmask == nullptr;
   if (fused_mask) {
     const float *hb = a.heat + (size_t)b * HW;
+    const bool logits = (a.flags & 8) != 0;   // probabilities formed once, on the way into LDS
     if ((HW & 3) == 0) {
       // 16-byte loads, 8 per thread in flight (8192 pixels = 2048 float4)
       const float4 *hb4 = reinterpret_cast<const float4 *>(hb);
@@ -320,10 +335,14 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int q = tid + k * kBlock;
+        if (logits)
+          v[k] = make_float4(heat_prob(v[k].x), heat_prob(v[k].y), heat_prob(v[k].z),
+                             heat_prob(v[k].w));
         if (q < n4) sh4[q] = v[k];
       }
     } else {
-      for (int p = tid; p < (int)HW; p += kBlock) s_heat[p] = hb[p];
+      for (int p = tid; p < (int)HW; p += kBlock)
+        s_heat[p] = logits ? heat_prob(hb[p]) : hb[p];
     }
     __syncthreads();
     for (int p0 = 0; p0 < (int)HW; p0 += kBlock) {
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       if (idx < (int)HW) {
         const int y = idx / W;
         const int x = idx - y * W;
-        is_kpt = heat_nms(s_heat, a.H, W, y, x, (a.flags & 2) != 0) > a.kpt_thr;
+        is_kpt = heat_nms<false>(s_heat, a.H, W, y, x, (a.flags & 2) != 0) > a.kpt_thr;
       }
       const unsigned long long m = __ballot(is_kpt);
       if (lane == 0 && (idx >> 6) < a.nwords) s_mask[idx >> 6] = m;
@@ -735,7 +754,7 @@ int decode_batch_launch(const float *heat, const float *offset, const float *err
   if (!fused_mask) {
     dim3 g1((HW + kBlock - 1) / kBlock, p->B);
     hipLaunchKernelGGL(decode_mask_kernel, g1, dim3(kBlock), 0, s, heat, HW,
-                       p->W, p->kpt_thr, kmask, nwords, p->flags & 2,
+                       p->W, p->kpt_thr, kmask, nwords, p->flags & 2, p->flags & 8,
                        split ? out->counts : nullptr);
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }

@@ -163,14 +163,17 @@ def _params(B, H, W, thr, root_thr, cluster_thr, by_center_thr, caps, flags=0):
     return p
 
 
-FLAG_NO_GROUP, FLAG_NMS_3X3, FLAG_NEAREST = 1, 2, 4
+FLAG_NO_GROUP, FLAG_NMS_3X3, FLAG_NEAREST, FLAG_LOGITS = 1, 2, 4, 8
 
 
 def decode_batch(heat, offset, error, thr=0.1, root_thr=1, cluster_thr=4,
                  cluster_by_center_thr=None, group=True, max_kpts=None,
                  max_centers=None, max_groups=None, keep_device=False,
-                 nms_3x3=False, assign_nearest=False):
+                 nms_3x3=False, assign_nearest=False, logits=False):
     """Decode (and group) a batch on the GPU.
+
+    logits: `heat` is the head's raw keypoint map; clamp(sigmoid(.), 1e-4, 1 - 1e-4)
+    (ganet_head.py:291) is applied on the device as the plane is read.
 
     nms_3x3 / assign_nearest: non-default variants with no counterpart in the
     reference's code (3x3 heat-map NMS instead of its 1x3, nearest centre within the
@@ -195,7 +198,8 @@ def decode_batch(heat, offset, error, thr=0.1, root_thr=1, cluster_thr=4,
         p = _params(B, H, W, thr, root_thr, cluster_thr, cluster_by_center_thr,
                     caps, flags=(0 if group else FLAG_NO_GROUP) |
                     (FLAG_NMS_3X3 if nms_3x3 else 0) |
-                    (FLAG_NEAREST if assign_nearest else 0))
+                    (FLAG_NEAREST if assign_nearest else 0) |
+                    (FLAG_LOGITS if logits else 0))
         with torch.cuda.device(heat.device):
             bufs = DecodeBuffers(B, caps[0], caps[1], caps[2], heat.device)
             ws_bytes = L.ganet_decode_workspace_bytes(ctypes.byref(p))

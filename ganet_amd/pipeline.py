@@ -28,7 +28,7 @@ class HotPath(object):
                  channels_last=True, mfma_bf16=False, fuse_relu=True,
                  offset_is_points=True, expect_kpts=192, expect_centers=16,
                  overlap_copy=False, ablate=0, algo=0, pack_to_host=True,
-                 side_decode=False):
+                 side_decode=False, heat_is_logits=False):
         self.L = _lib.lib()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.B, self.H, self.W, self.K = B, H, W, K
@@ -66,7 +66,10 @@ class HotPath(object):
                 else torch.contiguous_format)
             by_center = by_center_thr is not None
             caps = (max_kpts, max_centers, max_centers if by_center else max_kpts)
-            self.dp = _params(B, H, W, thr, root_thr, cluster_thr, by_center_thr, caps)
+            # heat_is_logits: the head's raw keypoint map goes in; clamp(sigmoid(.)) of
+            # ganet_head.py:291 happens inside the decode (ganet_decode_params.flags bit3)
+            self.dp = _params(B, H, W, thr, root_thr, cluster_thr, by_center_thr, caps,
+                              flags=8 if heat_is_logits else 0)
             # two result blocks + pinned mirrors: the D2H copy of step i runs on a
             # copy stream while step i+1 computes
             self.slots = []

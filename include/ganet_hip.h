@@ -233,7 +233,17 @@ typedef struct {
                                  instead of the reference's 1x3 (ganet_head.py:205-208);
                            bit2: a keypoint joins the NEAREST group centre within the
                                  threshold (ties: lower index) instead of the first
-                                 one (post_process.py:61-66) */
+                                 one (post_process.py:61-66)
+                           bit3: `heat` holds the head's LOGITS; every value read goes
+                                 through clamp(sigmoid(v), 1e-4, 1 - 1e-4) first, the line
+                                 in front of the decode in forward_test
+                                 (mmdet/models/dense_heads/ganet_head.py:291), so that pass
+                                 over the plane and its launch go away.  float32,
+                                 1 / (1 + exp(-v)) like ATen's GPU kernel; a sigmoid from
+                                 another library can differ in the last bit, which only
+                                 matters for a value within one ulp of kpt_thr or of a
+                                 neighbour (checked bit-exact against torch's own sigmoid
+                                 on this GPU, tests/test_gpu_decode.py) */
   int32_t reserved[4];
 } ganet_decode_params;
 

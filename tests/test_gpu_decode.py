@@ -154,3 +154,35 @@ def test_size_independent_properties_dense_s4():
     c, kxy, al, rt = O.decode(heat[0], off[0], err[0], cfg["thr"], 1.0)
     gid, means, cgid, ng = O.group_fast(c, rt, T, T)
     check_image_against(r1.image(0), c, al, rt, gid, means, ng)
+
+
+@pytest.mark.parametrize("shape,B", [("s8_culane", 16), ("dense_s8", 4)])
+def test_logits_prologue_matches_torch_sigmoid_clamp(shape, B):
+    """flags bit3: the decode reads the head's logits and applies
+    clamp(sigmoid(.), 1e-4, 1 - 1e-4) (ganet_head.py:291) itself.  Checked bit-exact
+    against the reference's own order on this GPU - torch's sigmoid and clamp, then the
+    decode on probabilities - and against the oracle on those probabilities.  Small maps
+    take the one-kernel form (plane staged in LDS), large ones decode_mask_kernel."""
+    cfg = synth.SHAPES[shape]
+    heat, off, err = synth.decode_inputs(B, cfg["H"], cfg["W"], lanes=cfg["lanes"], seed=5)
+    logit = np.log(heat.astype(np.float64) / (1.0 - heat.astype(np.float64))).astype(np.float32)
+    # saturated, clamped and non-finite logits in image 0
+    logit[0, 0, 0, :8] = [100.0, -100.0, 20.0, -20.0, np.inf, -np.inf, np.nan, 9.3]
+    logit[0, 0, 3, 5:9] = 12.0     # a plateau that the clamp flattens to 1 - 1e-4
+    lg = cuda(logit)
+    prob = torch.clamp(lg.sigmoid(), min=1e-4, max=1 - 1e-4)
+    T = float(cfg["T"])
+    kw = dict(thr=cfg["thr"], root_thr=cfg["root_thr"], cluster_thr=T, cluster_by_center_thr=T)
+    got = D.decode_batch(lg, cuda(off), cuda(err), logits=True, **kw)
+    ref = D.decode_batch(prob, cuda(off), cuda(err), **kw)
+    ph = prob.cpu().numpy()
+    total = 0
+    for b in range(B):
+        g, r = got.image(b), ref.image(b)
+        for k in ("centers", "kpt_xy", "align", "root", "kpt_gid", "group_center", "group_count"):
+            assert np.asarray(g[k]).tobytes() == np.asarray(r[k]).tobytes(), (b, k)
+        c, kxy, al, rt = O.decode(ph[b], off[b], err[b], cfg["thr"], cfg["root_thr"])
+        gid, means, cgid, ng = O.group_fast(c, rt, T, T)
+        check_image_against(g, c, al, rt, gid, means, ng)
+        total += len(kxy)
+    assert total > 50 * B
