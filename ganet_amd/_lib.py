@@ -39,7 +39,7 @@ class LaneFormat(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "by_center", "downscale", "points_thr", "float32_scalars", "threads",
         "img_h", "img_w")] + [(n, ctypes.c_double) for n in (
-            "crop_x0", "crop_y0", "crop_x1", "crop_y1")]
+            "crop_x0", "crop_y0", "crop_x1", "crop_y1")] + [("packed_words", ctypes.c_int64)]
 
 
 class DcnParams(ctypes.Structure):

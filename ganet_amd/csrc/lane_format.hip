@@ -29,15 +29,19 @@ struct ImageView {
 };
 
 // record b of ganet_decode_pack (include/ganet_hip.h); false if the record is unusable
-bool view_image(const int32_t *packed, int B, int b, int by_center, ImageView *v) {
+bool view_image(const int32_t *packed, long long packed_words, int B, int b, int by_center,
+                ImageView *v) {
   const int32_t *h = packed + (size_t)b * 8;
   if (h[3] & 15) return false;   // capacity overflow / record not packed
+  if (h[0] < 0 || h[1] < 0 || h[2] < 0 || h[4] < 0 || h[5] < 0) return false;
   const int32_t *r = packed + (size_t)B * 8 + h[4];
   v->nk = h[0];
   v->nc = h[1];
   v->ng = h[2];
   v->ngc = by_center ? v->ng : 0;
-  if (h[5] != 7 * v->nk + 3 * v->nc + 2 * v->ngc + v->ng) return false;
+  if ((long long)h[5] != 7ll * v->nk + 3ll * v->nc + 2ll * v->ngc + v->ng) return false;
+  // the record has to lie inside the caller's buffer
+  if (8ll * B + h[4] + h[5] > packed_words) return false;
   v->kpt_align = r + 2 * (size_t)v->nk;
   v->kpt_root = r + 4 * (size_t)v->nk;
   v->kpt_gid = r + 6 * (size_t)v->nk;
@@ -100,10 +104,20 @@ void for_images(int B, int threads, long long work, F f) {
     return;
   }
   std::vector<std::thread> pool;
-  for (int t = 0; t < threads; ++t)
-    pool.emplace_back([=]() {
-      for (int b = t; b < B; b += threads) f(b);
-    });
+  pool.reserve(threads);
+  int started = 0;
+  for (; started < threads; ++started) {
+    const int t = started;
+    try {
+      pool.emplace_back([=]() {
+        for (int b = t; b < B; b += threads) f(b);
+      });
+    } catch (...) {   // no more threads to be had: the calling thread takes the rest
+      break;
+    }
+  }
+  for (int t = started; t < threads; ++t)
+    for (int b = t; b < B; b += threads) f(b);
   for (auto &th : pool) th.join();
 }
 
@@ -137,23 +151,32 @@ inline char *put_int_2f(char *p, int32_t v) {
   return p;
 }
 
-}  // namespace
+// no C++ exception may cross the C boundary: out of memory reads as a workspace error
+template <typename F>
+int guarded(F body) {
+  try {
+    return body();
+  } catch (...) {
+    return GANET_ERR_WORKSPACE;
+  }
+}
 
-extern "C" int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_format *f,
-                                       int32_t *lanes, size_t lanes_words, size_t *needed_words) {
+int lanes_from_packed(const int32_t *packed, const ganet_lane_format *f, int32_t *lanes,
+                      size_t lanes_words, size_t *needed_words) {
   if (!packed || !f || !needed_words) return GANET_ERR_NULL;
   const int B = f->B;
   if (B <= 0 || f->img_h <= 0 || f->img_w <= 0 || f->downscale <= 0) return GANET_ERR_BAD_SHAPE;
+  if (f->packed_words < 8ll * B) return GANET_ERR_BAD_SHAPE;
   const Scale sx = {(f->crop_x1 - f->crop_x0) / (double)f->img_w, f->crop_x0, f->float32_scalars};
   const Scale sy = {(f->crop_y1 - f->crop_y0) / (double)f->img_h, f->crop_y0, f->float32_scalars};
 
   long long work = 0;
-  for (int b = 0; b < B; ++b) work += packed[(size_t)b * 8];
+  for (int b = 0; b < B; ++b) work += packed[(size_t)b * 8] > 0 ? packed[(size_t)b * 8] : 0;
   // pass 1: members per group -> lanes kept and words per image
   std::vector<int> words(B, 0), nlanes(B, 0), bad(B, 0);
   for_images(B, f->threads, work, [&](int b) {
     ImageView v;
-    if (!view_image(packed, B, b, f->by_center, &v)) {
+    if (!view_image(packed, f->packed_words, B, b, f->by_center, &v)) {
       bad[b] = 1;
       return;
     }
@@ -182,7 +205,7 @@ extern "C" int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_f
   for (int b = 0; b < B; ++b) {
     int32_t *h = lanes + (size_t)b * 4;
     ImageView v;
-    view_image(packed, B, b, f->by_center, &v);
+    view_image(packed, f->packed_words, B, b, f->by_center, &v);
     h[0] = nlanes[b];
     h[1] = v.ngc;
     h[2] = (int32_t)off;
@@ -193,7 +216,7 @@ extern "C" int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_f
   // pass 2: the lanes in group order, their points in keypoint order
   for_images(B, f->threads, work, [&](int b) {
     ImageView v;
-    view_image(packed, B, b, f->by_center, &v);
+    view_image(packed, f->packed_words, B, b, f->by_center, &v);
     int32_t *rec = lanes + (size_t)B * 4 + lanes[(size_t)b * 4 + 2];
     std::vector<int> cnt(v.ng > 0 ? v.ng : 0, 0), start(v.ng > 0 ? v.ng : 0, -1);
     for (int k = 0; k < v.nk; ++k) {
@@ -232,14 +255,14 @@ extern "C" int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_f
   return GANET_OK;
 }
 
-extern "C" int ganet_tusimple_from_lanes(const int32_t *lanes, int B, const int32_t *h_samples,
-                                         int n_h, int reg_x, int threads, int32_t *xs,
-                                         size_t xs_words, int32_t *lane_start) {
+int tusimple_from_lanes(const int32_t *lanes, int B, const int32_t *h_samples, int n_h, int reg_x,
+                        int threads, int32_t *xs, size_t xs_words, int32_t *lane_start) {
   if (!lanes || !h_samples || !xs || !lane_start) return GANET_ERR_NULL;
   if (B <= 0 || n_h < 0) return GANET_ERR_BAD_SHAPE;
   lane_start[0] = 0;
   for (int b = 0; b < B; ++b) lane_start[b + 1] = lane_start[b] + lanes[(size_t)b * 4];
   if (xs_words < (size_t)lane_start[B] * (size_t)n_h) return GANET_ERR_WORKSPACE;
+  std::vector<int> bad(B, 0);
   for_images(B, threads, (long long)lane_start[B] * n_h * 4, [&](int b) {
     const int32_t *rec = lanes + (size_t)B * 4 + lanes[(size_t)b * 4 + 2];
     int pos = 0;
@@ -254,9 +277,12 @@ extern "C" int ganet_tusimple_from_lanes(const int32_t *lanes, int B, const int3
           const int x0 = pts[2 * i], y0 = pts[2 * i + 1], x1 = pts[2 * i + 2], y1 = pts[2 * i + 3];
           const int lo = y0 < y1 ? y0 : y1, hi = y0 < y1 ? y1 : y0;
           if (lo <= y && y <= hi && lo != hi) {
-            const double k = (double)(x1 - x0) / (double)(y1 - y0);
-            const double t = k * (double)(y - y0);
-            x = (int)std::trunc(t + (double)x0 + 0.49999);
+            // Python integers: the differences are formed without wrap-around
+            const double k = ((double)x1 - (double)x0) / ((double)y1 - (double)y0);
+            const double t = k * ((double)y - (double)y0);
+            int32_t xi;
+            if (!to_int(t + (double)x0 + 0.49999, &xi)) bad[b] = 1;
+            else x = xi;
             break;
           }
         }
@@ -265,11 +291,13 @@ extern "C" int ganet_tusimple_from_lanes(const int32_t *lanes, int B, const int3
       pos += 2 + 4 * n;
     }
   });
+  for (int b = 0; b < B; ++b)
+    if (bad[b]) return GANET_ERR_NOT_FINITE;   // an x no int32 holds
   return GANET_OK;
 }
 
-extern "C" int ganet_culane_text(const int32_t *lanes, int B, int threads, char *text,
-                                 size_t text_bytes, size_t *text_start) {
+int culane_text(const int32_t *lanes, int B, int threads, char *text, size_t text_bytes,
+                size_t *text_start) {
   if (!lanes || !text_start) return GANET_ERR_NULL;
   if (B <= 0) return GANET_ERR_BAD_SHAPE;
   // worst case per point: two numbers of "-2147483648.00" and two separators
@@ -308,4 +336,24 @@ extern "C" int ganet_culane_text(const int32_t *lanes, int B, int threads, char 
   // text_start[b] keeps the start of image b's text; its length goes to the odd slots
   for (int b = 0; b < B; ++b) text_start[B + 1 + b] = used[b];
   return GANET_OK;
+}
+
+}  // namespace
+
+extern "C" int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_format *f,
+                                       int32_t *lanes, size_t lanes_words, size_t *needed_words) {
+  return guarded([&] { return lanes_from_packed(packed, f, lanes, lanes_words, needed_words); });
+}
+
+extern "C" int ganet_tusimple_from_lanes(const int32_t *lanes, int B, const int32_t *h_samples,
+                                         int n_h, int reg_x, int threads, int32_t *xs,
+                                         size_t xs_words, int32_t *lane_start) {
+  return guarded([&] {
+    return tusimple_from_lanes(lanes, B, h_samples, n_h, reg_x, threads, xs, xs_words, lane_start);
+  });
+}
+
+extern "C" int ganet_culane_text(const int32_t *lanes, int B, int threads, char *text,
+                                 size_t text_bytes, size_t *text_start) {
+  return guarded([&] { return culane_text(lanes, B, threads, text, text_bytes, text_start); });
 }

@@ -274,6 +274,7 @@ def format_batch(packed, B, by_center, downscale, crop_bbox, img_shape, points_t
     f.threads = threads or min(16, len(os.sched_getaffinity(0)))
     f.img_h, f.img_w = int(img_shape[0]), int(img_shape[1])
     f.crop_x0, f.crop_y0, f.crop_x1, f.crop_y1 = (float(v) for v in crop_bbox)
+    f.packed_words = packed.size
     need = ctypes.c_size_t(0)
     rc = L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), None, 0, ctypes.byref(need))
     if rc not in (_lib.GANET_OK, _lib.GANET_ERR_WORKSPACE):

@@ -349,7 +349,9 @@ int ganet_decode_pack(const ganet_decode_params *p, const ganet_decode_out *out,
  *                 then cluster_centers[2 * centres]
  * *needed_words is always set; GANET_ERR_WORKSPACE when lanes_words is smaller (lanes may be
  * NULL to query).  GANET_ERR_BAD_SHAPE for a record with capacity overflow bits set,
- * GANET_ERR_NOT_FINITE where Python's int() raises. */
+ * negative counts or an extent outside packed_words, GANET_ERR_NOT_FINITE where Python's
+ * int() raises (or yields an integer no int32 holds).  Host memory running out inside any of
+ * the three calls reads as GANET_ERR_WORKSPACE; no C++ exception leaves them. */
 typedef struct ganet_lane_format {
   int32_t B;
   int32_t by_center;        /* records carry group centres (cluster_by_center_thr given) */
@@ -359,6 +361,8 @@ typedef struct ganet_lane_format {
   int32_t threads;          /* host threads over images (<= 1: the calling thread) */
   int32_t img_h, img_w;     /* img_shape[:2], the network input */
   double crop_x0, crop_y0, crop_x1, crop_y1;   /* crop_bbox in original-image pixels */
+  int64_t packed_words;     /* int32 words in `packed` (>= 8*B): a record that does not lie
+                               inside is refused with GANET_ERR_BAD_SHAPE, not read */
 } ganet_lane_format;
 
 int ganet_lanes_from_packed(const int32_t *packed, const ganet_lane_format *f, int32_t *lanes,

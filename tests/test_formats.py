@@ -211,6 +211,7 @@ def test_lanes_from_packed_legacy_float64_scalars():
     f.B, f.by_center, f.downscale, f.points_thr, f.float32_scalars, f.threads = 1, 1, 8, 0, 0, 1
     f.img_h, f.img_w = 320, 800
     f.crop_x0, f.crop_y0, f.crop_x1, f.crop_y1 = 0.0, 270.0, 1640.0, 590.0
+    f.packed_words = packed.size
     need = ctypes.c_size_t(0)
     L = _lib.lib()
     L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), None, 0, ctypes.byref(need))
@@ -222,3 +223,36 @@ def test_lanes_from_packed_legacy_float64_scalars():
     a = (img["align"] * np.float32(8)).astype(np.float64)
     exp = np.stack([np.trunc(a[:, 0] * rx + 0), np.trunc(a[:, 1] * ry + 270)], 1).astype(np.int64)
     assert np.array_equal(pts, exp)
+
+
+def test_lanes_from_packed_refuses_records_outside_the_buffer():
+    """A record stream shorter than its headers claim (or with negative counts) is refused
+    with GANET_ERR_BAD_SHAPE instead of being read past its end."""
+    import ctypes
+    from ganet_amd import _lib
+    nk = 12
+    img = dict(kpt_gid=np.zeros(nk, np.int32), n_groups=1,
+               align=np.ones((nk, 2), np.float32), root=np.ones((nk, 2), np.float32),
+               group_center=np.array([[5, 9]], np.int32))
+    packed = formats.packed_from_images([img, img])
+    L = _lib.lib()
+
+    def call(buf, words):
+        f = _lib.LaneFormat()
+        f.B, f.by_center, f.downscale, f.points_thr, f.float32_scalars, f.threads = 2, 1, 8, 0, 1, 1
+        f.img_h, f.img_w = 320, 800
+        f.crop_x0, f.crop_y0, f.crop_x1, f.crop_y1 = 0.0, 270.0, 1640.0, 590.0
+        f.packed_words = words
+        need = ctypes.c_size_t(0)
+        return L.ganet_lanes_from_packed(buf.ctypes.data, ctypes.byref(f), None, 0,
+                                         ctypes.byref(need))
+
+    assert call(packed, packed.size) == _lib.GANET_ERR_WORKSPACE      # the size query
+    assert call(packed, packed.size - 1) == _lib.GANET_ERR_BAD_SHAPE  # last record cut short
+    assert call(packed, 8) == _lib.GANET_ERR_BAD_SHAPE                # not even the headers
+    neg = packed.copy()
+    neg[0] = -5
+    assert call(neg, neg.size) == _lib.GANET_ERR_BAD_SHAPE
+    far = packed.copy()
+    far[8 + 4] = 1 << 30                                               # record offset far outside
+    assert call(far, far.size) == _lib.GANET_ERR_BAD_SHAPE
