@@ -713,7 +713,11 @@ int stream_forward(const void *xh, const float *offset, const float *mask, const
     a.offset = offset + (size_t)b0 * 2 * T * HW;
     a.mask = mask ? mask + (size_t)b0 * T * HW : nullptr;
     a.out = static_cast<unsigned char *>(out) + (size_t)b0 * HW * p->Cout * out_es;
-    if (hipMemsetAsync(ws, 0, ctl_bytes, s) != hipSuccess) return GANET_ERR_HIP;
+    // the status word (CTL_ERROR, word 0) is cleared once per call: a later chunk must not
+    // erase the failure of an earlier one (its workgroups see the word and stop at once)
+    const size_t keep = b0 == 0 ? 0 : 4;
+    if (hipMemsetAsync(static_cast<unsigned char *>(ws) + keep, 0, ctl_bytes - keep, s) != hipSuccess)
+      return GANET_ERR_HIP;
     int rc;
     if (ta == GANET_BF16 && p->dtype == GANET_F32)
       rc = stream_launch<bf16_t, float>(a, Cp, cus, s);

@@ -85,3 +85,14 @@ def test_algo3_refused_where_it_does_not_apply():
     x, off, w, pts = synth.lfa_inputs(2, 256, 8, 12, 7, seed=1)
     with pytest.raises(Exception):
         run(x, off, w, 7, 3, dtype=torch.float32)          # exact / split float32 arithmetic
+
+
+def test_algo3_several_launches_per_call(monkeypatch):
+    """A Y budget of 1 MB: the batch is walked in launches of 8 images (one per queue), the
+    last one ragged; the control block is cleared between them, the status word only once."""
+    monkeypatch.setenv("GANET_STREAM_Y_MB", "1")
+    B, Cin, H, W, K = 20, 128, 17, 23, 7
+    x, off, w, pts = synth.lfa_inputs(B, Cin, H, W, K, seed=4)
+    a3 = run(x, pts, w, K, 3, offset_is_points=True, fuse_relu=True)
+    monkeypatch.delenv("GANET_STREAM_Y_MB")
+    assert torch.equal(a3, run(x, pts, w, K, 2, offset_is_points=True, fuse_relu=True))
