@@ -294,7 +294,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # GANET_BENCH_FORCE_DIST: rehearsal of the RCCL rendezvous / barrier / max with one rank
+    if world > 1 or os.environ.get("GANET_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
