@@ -214,11 +214,24 @@ def spawn_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
                                       env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    worst = 0
-    for pr in procs:
-        rc = pr.wait()
-        if rc != 0 and worst == 0:
-            worst = rc if rc > 0 else 1
+    # a rank that dies leaves the others in a barrier: once one has failed, the rest (the
+    # exact processes started above) get a grace period and are then ended
+    worst, failed_at, live = 0, None, list(procs)
+    while live:
+        for pr in list(live):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            live.remove(pr)
+            if rc != 0 and worst == 0:
+                worst = rc if rc > 0 else 1
+                failed_at = time.monotonic()
+        if failed_at is not None and live and time.monotonic() - failed_at > float(
+                os.environ.get("GANET_BENCH_SPAWN_GRACE", "20")):
+            for pr in live:
+                pr.kill()
+            failed_at = time.monotonic() + 1e9
+        time.sleep(0.05)
     return worst
 
 
@@ -277,6 +290,10 @@ def main():
         print(json.dumps({k: os.environ.get(k) for k in
                           ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}),
               flush=True)
+        if os.environ["GANET_BENCH_SPAWN_ONLY"] == "rank1_dies":   # the others "wait in a barrier"
+            if os.environ.get("RANK") == "1":
+                raise SystemExit(3)
+            time.sleep(600)
         return
 
     rank = int(os.environ.get("RANK", "0"))

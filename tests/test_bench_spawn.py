@@ -39,3 +39,14 @@ def test_worst_rank_exit_code_is_returned():
 def test_launcher_world_size_must_match_gpus():
     r = _run({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "4")
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_a_dead_rank_does_not_leave_the_parent_waiting():
+    """Rank 1 exits with an error while the others would wait in a barrier for ever: the
+    parent gives them a grace period, ends them and returns the failed rank's code."""
+    import time
+    t0 = time.monotonic()
+    r = _run({"GANET_BENCH_SPAWN_ONLY": "rank1_dies", "GANET_BENCH_SPAWN_GRACE": "1"},
+             "--gpus", "3", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 3
+    assert time.monotonic() - t0 < 120

@@ -121,3 +121,21 @@ def test_decode_beside_the_lfa_on_a_second_stream():
     assert np.array_equal(r2.header, r2s.header)
     assert np.array_equal(r2.records, r2s.records)
     assert int(r2.header[:, 0].sum()) < int(r1.header[:, 0].sum())
+
+
+def test_step_on_logits_matches_step_on_probabilities():
+    """heat_is_logits: the step takes the head's raw keypoint map; the records must equal
+    those of the step fed with torch's own clamp(sigmoid(.)) of the same logits
+    (ganet_head.py:291)."""
+    B = 6
+    hp, d = build(B, torch.bfloat16)
+    hl, _ = build(B, torch.bfloat16, heat_is_logits=True)
+    logit = torch.logit(d["heat"].double()).float()
+    prob = torch.clamp(logit.sigmoid(), min=1e-4, max=1 - 1e-4)
+    hp.step(d["x"], d["pts"], prob, d["off"], d["err"])
+    rp = hp.result()
+    hl.step(d["x"], d["pts"], logit, d["off"], d["err"])
+    rl = hl.result()
+    assert np.array_equal(rp.header, rl.header)
+    assert np.array_equal(rp.records, rl.records)
+    assert int(rl.header[:, 0].sum()) > 50 * B
