@@ -279,6 +279,10 @@ def main():
                          "beside the enqueueing one")
     ap.add_argument("--format-threads", type=int, default=0,
                     help="host threads of the formatting routines (0: CPU share, at most 16)")
+    ap.add_argument("--result-blocks", type=int, default=2,
+                    help="result blocks of the step, used in turn: with --consume, step i+n is "
+                         "enqueued only after step i has been formatted")
+    ap.add_argument("--consume-threads", type=int, default=2)
     ap.add_argument("--overlap-copy", action="store_true",
                     help="copy the lane lists D2H on a second stream")
     args = ap.parse_args()
@@ -341,7 +345,8 @@ def main():
                  mfma_bf16={"auto": 0, "bf16": 1, "exact": 2}[args.fp32_mode],
                  side_decode=wl["decode"] and not (args.single_stream or args.graph
                                                    or args.overlap_copy),
-                 ablate=args.ablate, algo=args.algo, pack_to_host=not args.device_pack)
+                 ablate=args.ablate, algo=args.algo, pack_to_host=not args.device_pack,
+                 result_blocks=args.result_blocks)
     if args.pts == "zero":
         d["pts"].zero_()
     hp.set_weight(d["w"])
@@ -429,12 +434,12 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # --consume: two host threads format finished steps while this one enqueues the next
-    # (the library calls release the GIL); a result block is reused every second step, so
-    # step i+2 is enqueued only after step i has been formatted
+    # (the library calls release the GIL); the result blocks are used in turn, so step
+    # i + result_blocks is enqueued only after step i has been formatted
     pool, pending = None, {}
     if args.consume:
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=2)
+        pool = ThreadPoolExecutor(max_workers=args.consume_threads)
     for i in range(args.steps):
         if pool is not None and hp.cur in pending:
             nl, nb = pending.pop(hp.cur).result()
@@ -445,7 +450,7 @@ def main():
         else:
             one_step(events[i])
         if pool is not None:
-            pending[hp.cur ^ 1] = pool.submit(consume, hp.last)
+            pending[(hp.cur - 1) % len(hp.slots)] = pool.submit(consume, hp.last)
     for fut in pending.values():
         nl, nb = fut.result()
         consumed[0] += nl

@@ -28,7 +28,7 @@ class HotPath(object):
                  channels_last=True, mfma_bf16=False, fuse_relu=True,
                  offset_is_points=True, expect_kpts=192, expect_centers=16,
                  overlap_copy=False, ablate=0, algo=0, pack_to_host=True,
-                 side_decode=False, heat_is_logits=False):
+                 side_decode=False, heat_is_logits=False, result_blocks=2):
         self.L = _lib.lib()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.B, self.H, self.W, self.K = B, H, W, K
@@ -70,10 +70,12 @@ class HotPath(object):
             # ganet_head.py:291 happens inside the decode (ganet_decode_params.flags bit3)
             self.dp = _params(B, H, W, thr, root_thr, cluster_thr, by_center_thr, caps,
                               flags=8 if heat_is_logits else 0)
-            # two result blocks + pinned mirrors: the D2H copy of step i runs on a
-            # copy stream while step i+1 computes
+            # result blocks + pinned mirrors, used in turn: the D2H copy of step i runs
+            # while step i+1 computes, and a host thread may still be reading step i's
+            # records while steps up to i + result_blocks - 1 are enqueued
+            assert result_blocks >= 2
             self.slots = []
-            for _ in range(2):
+            for _ in range(result_blocks):
                 bufs = DecodeBuffers(B, caps[0], caps[1], caps[2], self.device)
                 # the async copy moves the header plus a budget of record words
                 # sized for the expected load; result() fetches any remainder
@@ -153,7 +155,7 @@ class HotPath(object):
             slot["direct"] = True
             slot["ready"].record(cur_stream)
             self.last = slot
-            self.cur ^= 1
+            self.cur = (self.cur + 1) % len(self.slots)
             return
         slot["direct"] = False
         slot["bufs"].pack(self.L, self.dp, cur_stream.cuda_stream)
@@ -170,7 +172,7 @@ class HotPath(object):
         slot["ready"].record(self.copy_stream if (copy_to_host and self.overlap_copy)
                              else cur_stream)
         self.last = slot
-        self.cur ^= 1
+        self.cur = (self.cur + 1) % len(self.slots)
 
     def step(self, x, pts, heat, offset, error):
         """One pass of the hot path.  Lifetime contract with side_decode: decode, grouping and
@@ -221,7 +223,7 @@ class HotPath(object):
         with torch.cuda.graph(graph):
             self.cur = first                # the graph always writes this result block
             self.step(x, pts, heat, offset, error)
-        self.cur = first ^ 1
+        self.cur = (first + 1) % len(self.slots)
         return graph
 
     def result(self, slot=None):
@@ -252,7 +254,7 @@ class HotPath(object):
     def records(self, slot):
         """The record stream of a step (header + records, the layout of ganet_decode_pack)
         as a view of the pinned host block - the input of formats.format_batch.  Waits for
-        that step only; valid until the step after next reuses the block."""
+        that step only; valid until the block comes round again (result_blocks steps later)."""
         slot["ready"].synchronize()
         host, total = self._host_stream(slot)
         return host[:total]
