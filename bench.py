@@ -192,8 +192,24 @@ def lfa_backward_side_measurement(dev, Cin, H, W, K, B=32, steps=20):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
-        return {"what": "grad input+offset+weight, float32, channel-last, batch %d, %dx%d, K %d" % (B, H, W, K),
-                "ms": ms, "images_per_s": B / (ms * 1e-3), "steps": steps}
+        res = {"what": "grad input+offset+weight, float32, channel-last, batch %d, %dx%d, K %d" % (B, H, W, K),
+               "ms": ms, "images_per_s": B / (ms * 1e-3), "steps": steps}
+        # the same with the forward's per-tap products kept (GANET_DCN_ALGO_KEEP_Y)
+        keep = {}
+        dcn.deform_conv_forward(tx, toff, tw, (1, 1), pad, (1, 1), keep_y=keep)
+        if "y" in keep:
+            def run_y():
+                dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), pad, (1, 1), y_saved=keep["y"])
+            for _ in range(3):
+                run_y()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                run_y()
+            e1.record()
+            torch.cuda.synchronize()
+            res["ms_with_forward_products"] = e0.elapsed_time(e1) / steps
+        return res
     except Exception as exc:  # noqa: BLE001 - a side measurement must not break the line
         return {"error": repr(exc)}
 

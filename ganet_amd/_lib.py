@@ -20,6 +20,7 @@ GANET_ERR_NOT_FINITE = -7
 
 GANET_F32, GANET_BF16, GANET_F16 = 0, 1, 2
 GANET_NCHW, GANET_NHWC = 0, 1
+GANET_DCN_ALGO_KEEP_Y = 0x100
 DECODE_MAX_CENTERS = 2048
 DECODE_COUNT_STRIDE = 8
 
@@ -29,6 +30,7 @@ EXPORTS = (
     "ganet_deform_conv_packed_weight_bytes", "ganet_deform_conv_pack_weight",
     "ganet_decode_workspace_bytes", "ganet_decode_batch", "ganet_group_batch",
     "ganet_decode_pack", "ganet_deform_conv_algorithm", "ganet_deform_conv_status_offset",
+    "ganet_deform_conv_y_offset", "ganet_deform_conv_backward_y",
     "ganet_deform_conv_backward_workspace_bytes", "ganet_deform_conv_backward",
     "ganet_decode_batch_noalloc",
     "ganet_lanes_from_packed", "ganet_tusimple_from_lanes", "ganet_culane_text",
@@ -100,6 +102,8 @@ def lib():
         L.ganet_deform_conv_workspace_bytes.argtypes = [ctypes.POINTER(DcnParams)]
         L.ganet_deform_conv_status_offset.restype = ctypes.c_size_t
         L.ganet_deform_conv_status_offset.argtypes = [ctypes.POINTER(DcnParams)]
+        L.ganet_deform_conv_y_offset.restype = ctypes.c_size_t
+        L.ganet_deform_conv_y_offset.argtypes = [ctypes.POINTER(DcnParams)]
         L.ganet_deform_conv_algorithm.restype = ctypes.c_int
         L.ganet_deform_conv_algorithm.argtypes = [ctypes.POINTER(DcnParams)]
         L.ganet_deform_conv_forward.restype = ctypes.c_int
@@ -112,6 +116,10 @@ def lib():
         L.ganet_deform_conv_backward.argtypes = [
             ctypes.c_void_p] * 10 + [ctypes.POINTER(DcnParams), ctypes.c_void_p,
                                      ctypes.c_size_t, ctypes.c_void_p]
+        L.ganet_deform_conv_backward_y.restype = ctypes.c_int
+        L.ganet_deform_conv_backward_y.argtypes = [
+            ctypes.c_void_p] * 10 + [ctypes.POINTER(DcnParams), ctypes.c_void_p,
+                                     ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
         L.ganet_deform_conv_packed_weight_bytes.restype = ctypes.c_size_t
         L.ganet_deform_conv_packed_weight_bytes.argtypes = [ctypes.POINTER(DcnParams)]
         L.ganet_deform_conv_pack_weight.restype = ctypes.c_int

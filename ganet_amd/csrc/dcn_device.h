@@ -122,10 +122,12 @@ bool cts_applicable(const ganet_dcn_params *p, int Cp, int CoutP);
 // float32 tensors whose per-tap GEMM runs as three bf16 passes (weights packed as
 // a high and a low bf16 plane)
 bool cts_split(const ganet_dcn_params *p, int Cp);
-size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta);
+// images per chunk (Y of a chunk stays inside the Infinity Cache); Y bytes of nb images
+int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta);
+size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta, int nb);
 int cts_forward(const void *xh, const float *offset, const float *mask, const void *wq,
                 const void *bias, void *out, const ganet_dcn_params *p, int ta, int kc,
-                int Cp, int CoutP, int Ho, int Wo, void *ybuf, hipStream_t s);
+                int Cp, int CoutP, int Ho, int Wo, void *ybuf, int nb, hipStream_t s);
 
 // the same algorithm as one persistent launch (csrc/deform_conv_stream.hip): producer
 // workgroups contract, consumer workgroups sample, Y travels through a cache-resident ring

@@ -604,13 +604,21 @@ struct Plan {
   bool cts;      // contract-then-sample path (deform_conv_cts.hip)
   bool split;    // ... with float32 tensors contracted as three bf16 passes
   bool stream;   // ... as one persistent producer/consumer launch (deform_conv_stream.hip)
+  bool keep_y;   // the whole batch's per-tap products stay in the workspace (GANET_DCN_ALGO_KEEP_Y)
+  int nb;        // images per chunk of the contract-then-sample pair
   size_t xh_bytes, wp_bytes, y_bytes;
 };
 
 size_t dtype_size(int dt) { return dt == GANET_F32 ? 4 : 2; }
 
-int make_plan(const ganet_dcn_params *p, Plan *pl) {
-  if (!p) return GANET_ERR_NULL;
+int make_plan(const ganet_dcn_params *p_in, Plan *pl) {
+  if (!p_in) return GANET_ERR_NULL;
+  // `algo` carries the algorithm in its low byte and GANET_DCN_ALGO_KEEP_Y above it
+  ganet_dcn_params q = *p_in;
+  const bool keep_y = (q.algo & GANET_DCN_ALGO_KEEP_Y) != 0;
+  if (q.algo < 0 || (q.algo & ~(0xff | GANET_DCN_ALGO_KEEP_Y))) return GANET_ERR_BAD_SHAPE;
+  q.algo &= 0xff;
+  const ganet_dcn_params *p = &q;
   if (p->B <= 0 || p->Cin <= 0 || p->H <= 0 || p->W <= 0 || p->Cout <= 0)
     return GANET_ERR_BAD_SHAPE;
   // shape_check, deform_conv_cuda.cpp:62-150
@@ -683,8 +691,19 @@ int make_plan(const ganet_dcn_params *p, Plan *pl) {
   pl->stream = pl->cts && p->algo == 3 &&
                stream_applicable(p, pl->ta, pl->Cp, pl->CoutP, pl->Ho, pl->Wo);
   if (p->algo == 3 && !pl->stream) return GANET_ERR_UNSUPPORTED;
+  // keeping Y for the backward: float32 tensors in the default arithmetic (the backward forms
+  // the same three-pass products), one chunk for the whole batch
+  pl->keep_y = keep_y;
+  if (keep_y && (!pl->split || pl->stream || p->Cout % 64)) return GANET_ERR_UNSUPPORTED;
+  pl->nb = 0;
+  if (pl->cts && !pl->stream) {
+    pl->nb = keep_y ? p->B : cts_chunk_images(p, pl->CoutP, pl->ta);
+    const unsigned long long img_y = (unsigned long long)p->H * p->W * pl->T * pl->CoutP *
+                                     dtype_size(pl->ta);
+    if (img_y * (unsigned long long)pl->nb >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
+  }
   pl->y_bytes = pl->stream ? stream_workspace_bytes(p, pl->CoutP)
-                           : (pl->cts ? cts_y_bytes(p, pl->CoutP, pl->ta) : 0);
+                           : (pl->cts ? cts_y_bytes(p, pl->CoutP, pl->ta, pl->nb) : 0);
   return GANET_OK;
 }
 
@@ -774,6 +793,12 @@ extern "C" size_t ganet_deform_conv_status_offset(const ganet_dcn_params *p) {
   return pl.xh_bytes;   // the control block's first word (CTL_ERROR) leads algorithm 3's scratch
 }
 
+extern "C" size_t ganet_deform_conv_y_offset(const ganet_dcn_params *p) {
+  Plan pl;
+  if (!p || make_plan(p, &pl) != GANET_OK || !pl.keep_y) return (size_t)-1;
+  return pl.xh_bytes;
+}
+
 extern "C" size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p) {
   Plan pl;
   if (make_plan(p, &pl) != GANET_OK) return 0;
@@ -859,7 +884,7 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
                           pl.CoutP, ybuf, s);
   if (pl.cts)
     return cts_forward(pl.copy_x ? xh : x, offset, mask, wp, bias, out, p, pl.ta, pl.kc,
-                       pl.Cp, pl.CoutP, pl.Ho, pl.Wo, ybuf, s);
+                       pl.Cp, pl.CoutP, pl.Ho, pl.Wo, ybuf, pl.nb, s);
 
   DcnArgs a;
   a.xh = pl.copy_x ? xh : x;

@@ -1052,8 +1052,11 @@ struct BwdPlan {
   }
 };
 
-int make_bwd_plan(const ganet_dcn_params *p, BwdPlan *pl) {
-  if (!p) return GANET_ERR_NULL;
+int make_bwd_plan(const ganet_dcn_params *p_in, BwdPlan *pl) {
+  if (!p_in) return GANET_ERR_NULL;
+  ganet_dcn_params q = *p_in;   // the forward's GANET_DCN_ALGO_KEEP_Y bit means nothing here
+  q.algo &= 0xff;
+  const ganet_dcn_params *p = &q;
   if (p->B <= 0 || p->Cin <= 0 || p->H <= 0 || p->W <= 0 || p->Cout <= 0)
     return GANET_ERR_BAD_SHAPE;
   if (p->kH <= 0 || p->kW <= 0 || p->sH <= 0 || p->sW <= 0 || p->dH <= 0 || p->dW <= 0 ||
@@ -1159,13 +1162,11 @@ extern "C" size_t ganet_deform_conv_backward_workspace_bytes(const ganet_dcn_par
   return pl.total();
 }
 
-extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
-                                          const float *mask, const void *weight,
-                                          const void *grad_out, void *grad_x,
-                                          float *grad_offset, float *grad_mask,
-                                          void *grad_weight, void *grad_bias,
-                                          const ganet_dcn_params *p, void *workspace,
-                                          size_t workspace_bytes, ganet_stream_t stream) {
+namespace {
+int backward_impl(const void *x, const float *offset, const float *mask, const void *weight,
+                  const void *grad_out, void *grad_x, float *grad_offset, float *grad_mask,
+                  void *grad_weight, void *grad_bias, const ganet_dcn_params *p, void *workspace,
+                  size_t workspace_bytes, ganet_stream_t stream, const float *y_saved) {
   if (!x || !offset || !weight || !grad_out || !p || !workspace) return GANET_ERR_NULL;
   const bool need_in = grad_x != nullptr || grad_offset != nullptr;
   if (need_in && (!grad_x || !grad_offset)) return GANET_ERR_NULL;  // computed together
@@ -1176,6 +1177,9 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
   if (rc != GANET_OK) return rc;
   const size_t need = pl.total();
   if (workspace_bytes < need) return GANET_ERR_WORKSPACE;
+  // the forward's per-tap products: float32 tensors on the commuted form only (they are the
+  // products this function would otherwise form again from x and the weights)
+  if (y_saved && (!pl.commuted || p->dtype != GANET_F32)) return GANET_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   float *xh = reinterpret_cast<float *>(ws);
@@ -1284,7 +1288,10 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
       const int nimg = p->B - img0 < pl.nb ? p->B - img0 : pl.nb;
       const long long M = (long long)nimg * HW;
       const float *xc = a.xh + (size_t)img0 * HW * pl.Cp;
-      if (need_in) {
+      const float *yc = yb;
+      if (need_in && y_saved) {
+        yc = y_saved + (size_t)img0 * HW * N;   // kept by the forward: [B][H*W][T*Cout]
+      } else if (need_in) {
         // per-tap products: three bf16 passes over high/low splits (as the forward forms them)
         const int rc2 = cts_gemm_f32_split(xc, wsp, yb, M, pl.Cp, N, s);
         if (rc2 != GANET_OK) return rc2;
@@ -1298,7 +1305,7 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
                           !getenv("GANET_BWD_SCATTER_ATOMIC");
       if (!binned && hipMemsetAsync(gyb, 0, (size_t)M * N * 4, s) != hipSuccess) return GANET_ERR_HIP;
       BwdCtsArgs c;
-      c.y = need_in ? yb : nullptr;
+      c.y = need_in ? yc : nullptr;
       c.gy = gyb;
       c.go = a.go;
       c.offset = offset;
@@ -1454,4 +1461,30 @@ extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
     if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
   }
   return GANET_OK;
+}
+}  // namespace
+
+extern "C" int ganet_deform_conv_backward(const void *x, const float *offset,
+                                          const float *mask, const void *weight,
+                                          const void *grad_out, void *grad_x,
+                                          float *grad_offset, float *grad_mask,
+                                          void *grad_weight, void *grad_bias,
+                                          const ganet_dcn_params *p, void *workspace,
+                                          size_t workspace_bytes, ganet_stream_t stream) {
+  return backward_impl(x, offset, mask, weight, grad_out, grad_x, grad_offset, grad_mask,
+                       grad_weight, grad_bias, p, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int ganet_deform_conv_backward_y(const void *x, const float *offset,
+                                            const float *mask, const void *weight,
+                                            const void *grad_out, void *grad_x,
+                                            float *grad_offset, float *grad_mask,
+                                            void *grad_weight, void *grad_bias,
+                                            const ganet_dcn_params *p, void *workspace,
+                                            size_t workspace_bytes, ganet_stream_t stream,
+                                            const void *y_saved) {
+  if (!y_saved) return GANET_ERR_NULL;
+  return backward_impl(x, offset, mask, weight, grad_out, grad_x, grad_offset, grad_mask,
+                       grad_weight, grad_bias, p, workspace, workspace_bytes, stream,
+                       static_cast<const float *>(y_saved));
 }

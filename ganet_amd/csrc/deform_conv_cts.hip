@@ -1210,25 +1210,25 @@ int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta) {
   return (int)(((size_t)p->B + chunks - 1) / chunks);
 }
 
-size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta) {
+size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta, int nb) {
   const size_t es = ta == GANET_F32 ? 4 : 2;
   const size_t per_img = (size_t)p->H * p->W * p->kH * p->kW * CoutP * es;
-  return ganet_align_up(per_img * cts_chunk_images(p, CoutP, ta), 256);
+  return ganet_align_up(per_img * (size_t)nb, 256);
 }
 
 // xh: NHWC map in arithmetic dtype `ta` with Cp channels; wq: packed weights
 // [T][CoutP][Cp] (same layout the fused kernel uses); ybuf: cts_y_bytes() of scratch.
 int cts_forward(const void *xh, const float *offset, const float *mask, const void *wq,
                 const void *bias, void *out, const ganet_dcn_params *p, int ta, int kc,
-                int Cp, int CoutP, int Ho, int Wo, void *ybuf, hipStream_t s) {
+                int Cp, int CoutP, int Ho, int Wo, void *ybuf, int nb, hipStream_t s) {
   const bool split = ta == GANET_F32 && cts_split(p, Cp);
   const int T = p->kH * p->kW;
   const int N = T * CoutP;
   const size_t es = ta == GANET_F32 ? 4 : 2;
   const size_t img_y = (size_t)p->H * p->W * N * es;
   if (img_y >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
-  const int nb = cts_chunk_images(p, CoutP, ta);
-  if ((size_t)nb * img_y >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
+  // nb images per chunk (cts_chunk_images, or the whole batch when Y is kept for the backward)
+  if (nb < 1 || (size_t)nb * img_y >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
   for (int img0 = 0; img0 < p->B; img0 += nb) {
     const int nimg = (p->B - img0) < nb ? (p->B - img0) : nb;
     const long long M = (long long)nimg * p->H * p->W;

@@ -43,6 +43,12 @@ class _Config(object):
     # (data_ptr, _version) is unchanged.  Off by default: writes through
     # `weight.data` do not bump `_version`, so a stale copy could be used.
     cache_packed_weights = False
+    # Training (float32 tensors, the LFA's shapes): the forward leaves its per-tap products
+    # in its workspace and the backward reads them instead of contracting x again
+    # (GANET_DCN_ALGO_KEEP_Y / ganet_deform_conv_backward_y).  The workspace then lives until
+    # the backward: B*H*W*kH*kW*Cout*4 bytes, kept only up to keep_y_max_bytes.
+    keep_y_for_backward = True
+    keep_y_max_bytes = 1 << 30
 
 
 config = _Config()
@@ -89,9 +95,13 @@ def _packed_weight(L, weight, p):
 def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
                         dilation=(1, 1), groups=1, deformable_groups=1,
                         mask=None, bias=None, fuse_relu=False,
-                        offset_is_points=False, mfma_bf16=None, algo=0, check=False):
+                        offset_is_points=False, mfma_bf16=None, algo=0, check=False,
+                        keep_y=None):
     """Raw forward on the HIP library.  `input` NCHW (contiguous or
     channels_last) on a GPU; returns a tensor of the same memory format.
+    keep_y: a dict; where the library can keep the per-tap products of the whole batch
+    (GANET_DCN_ALGO_KEEP_Y) it gets keep_y["y"] = that float32 tensor (a view of the call's
+    workspace) for deform_conv_backward(..., y_saved=...), otherwise it stays empty.
     check=True synchronises and raises if the algorithm left a failure word in its
     workspace (algorithm 3 only: ganet_deform_conv_status_offset)."""
     if not input.is_cuda:
@@ -137,6 +147,13 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
     p.fuse_relu = 1 if fuse_relu else 0
     p.offset_is_points = 1 if offset_is_points else 0
     p.algo = algo
+    y_off = None
+    if keep_y is not None and algo in (0, 2):
+        p.algo = algo | _lib.GANET_DCN_ALGO_KEEP_Y
+        y_off = L.ganet_deform_conv_y_offset(ctypes.byref(p))
+        if (y_off == ctypes.c_size_t(-1).value
+                or B * H * W * kH * kW * Cout * 4 > config.keep_y_max_bytes):
+            p.algo, y_off = algo, None
     Ho = L.ganet_dcn_out_size(H, p.pH, p.dH, kH, p.sH)
     Wo = L.ganet_dcn_out_size(W, p.pW, p.dW, kW, p.sW)
     if Ho < 1 or Wo < 1:
@@ -177,6 +194,9 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
     if rc == _lib.GANET_ERR_BAD_SHAPE and mask is None and (H < kH or W < kW):
         raise RuntimeError("input image is smaller than kernel")
     _lib.check(rc, "ganet_deform_conv_forward")
+    if y_off is not None:
+        nbytes = B * H * W * kH * kW * Cout * 4
+        keep_y["y"] = ws[y_off:y_off + nbytes].view(torch.float32)
     if check:
         off = L.ganet_deform_conv_status_offset(ctypes.byref(p))
         if off != ctypes.c_size_t(-1).value:
@@ -190,12 +210,14 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
 def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
                          padding=(0, 0), dilation=(1, 1), groups=1, deformable_groups=1,
                          mask=None, need_input=True, need_weight=True, need_bias=False,
-                         algo=0):
+                         algo=0, y_saved=None):
     """Raw backward on the HIP library (float32).  Returns
     (grad_input, grad_offset, grad_mask, grad_weight, grad_bias); entries that were not
     asked for (or have no meaning without a mask) are None.  grad_input has the memory
     format of `input`.  algo: 0 automatic, 1 direct (columns formed and consumed on chip),
-    2 commuted (Cout-wide rows through the per-tap products; where it applies)."""
+    2 commuted (Cout-wide rows through the per-tap products; where it applies).
+    y_saved: the forward's kept per-tap products (deform_conv_forward(keep_y=...)) of the
+    same input, offset and weight; used where the commuted form runs, ignored elsewhere."""
     if not grad_output.is_cuda or not input.is_cuda:
         raise NotImplementedError
     if input.dtype not in _DTYPES:
@@ -247,11 +269,17 @@ def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
         ws_bytes = L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(p))
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=input.device)
         stream = torch.cuda.current_stream(input.device).cuda_stream
-        rc = L.ganet_deform_conv_backward(
-            input.data_ptr(), offset.data_ptr(), ptr(mask), weight.data_ptr(),
-            grad_output.data_ptr(), ptr(grad_input), ptr(grad_offset), ptr(grad_mask),
-            ptr(grad_weight), ptr(grad_bias), ctypes.byref(p), ws.data_ptr(),
-            max(ws_bytes, 256) if ws_bytes else 0, stream)
+        args = (input.data_ptr(), offset.data_ptr(), ptr(mask), weight.data_ptr(),
+                grad_output.data_ptr(), ptr(grad_input), ptr(grad_offset), ptr(grad_mask),
+                ptr(grad_weight), ptr(grad_bias), ctypes.byref(p), ws.data_ptr(),
+                max(ws_bytes, 256) if ws_bytes else 0, stream)
+        rc = _lib.GANET_ERR_UNSUPPORTED
+        if y_saved is not None and need_input and input.dtype == torch.float32:
+            assert y_saved.is_cuda and y_saved.dtype == torch.float32 and y_saved.is_contiguous() \
+                and y_saved.numel() == B * H * W * kH * kW * Cout
+            rc = L.ganet_deform_conv_backward_y(*args, y_saved.data_ptr())
+        if rc == _lib.GANET_ERR_UNSUPPORTED:      # no saved products, or the direct form runs
+            rc = L.ganet_deform_conv_backward(*args)
     _lib.check(rc, "ganet_deform_conv_backward")
     return grad_input, grad_offset, grad_mask, grad_weight, grad_bias
 
@@ -268,6 +296,18 @@ def _check_im2col_step(im2col_step, batch):
     # the kernels do not chunk the batch; the reference's divisibility contract is kept
     # for API parity (deform_conv.py:49-51)
     assert batch % min(im2col_step, batch) == 0, 'im2col step must divide batchsize'
+
+
+def _keep_holder(ctx, input, n_coords):
+    """A dict for deform_conv_forward(keep_y=...) when this call's backward will form the
+    gradients of the input / offsets / mask (the part of the backward that reads the per-tap
+    products), None otherwise.  The tensors lead the Function's arguments: input, offset
+    (, mask)."""
+    if not config.keep_y_for_backward or input.dtype != torch.float32:
+        return None
+    if not any(ctx.needs_input_grad[:1 + n_coords]):
+        return None
+    return {}
 
 
 class DeformConvFunction(Function):
@@ -287,8 +327,11 @@ class DeformConvFunction(Function):
         if not input.is_cuda:
             raise NotImplementedError
         _check_im2col_step(im2col_step, input.shape[0])
-        return deform_conv_forward(input, offset, weight, ctx.stride, ctx.padding,
-                                   ctx.dilation, groups, deformable_groups)
+        kept = _keep_holder(ctx, input, 1)
+        out = deform_conv_forward(input, offset, weight, ctx.stride, ctx.padding,
+                                  ctx.dilation, groups, deformable_groups, keep_y=kept)
+        ctx.y_saved = kept.get("y") if kept is not None else None
+        return out
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -301,7 +344,8 @@ class DeformConvFunction(Function):
         g_in, g_off, _, g_w, _ = deform_conv_backward(
             input, offset, weight, grad_output, ctx.stride, ctx.padding, ctx.dilation,
             ctx.groups, ctx.deformable_groups, need_input=want[0] or want[1],
-            need_weight=want[2])
+            need_weight=want[2], y_saved=ctx.y_saved)
+        ctx.y_saved = None
         if g_off is not None:
             g_off = g_off.to(offset.dtype)
         return (g_in, g_off, g_w) + (None,) * 6
@@ -337,9 +381,12 @@ class ModulatedDeformConvFunction(Function):
             # when there is no bias (deform_conv.py:130-137)
             ctx.save_for_backward(input, offset, mask, weight,
                                   bias if ctx.with_bias else input.new_empty(1))
-        return deform_conv_forward(input, offset, weight, _pair(stride), _pair(padding),
-                                   _pair(dilation), groups, deformable_groups, mask=mask,
-                                   bias=bias)
+        kept = _keep_holder(ctx, input, 2)
+        out = deform_conv_forward(input, offset, weight, _pair(stride), _pair(padding),
+                                  _pair(dilation), groups, deformable_groups, mask=mask,
+                                  bias=bias, keep_y=kept)
+        ctx.y_saved = kept.get("y") if kept is not None else None
+        return out
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -350,7 +397,8 @@ class ModulatedDeformConvFunction(Function):
         grads = deform_conv_backward(
             input, offset, weight, grad_output, _pair(ctx.stride), _pair(ctx.padding),
             _pair(ctx.dilation), ctx.groups, ctx.deformable_groups, mask=mask,
-            need_input=True, need_weight=True, need_bias=ctx.with_bias)
+            need_input=True, need_weight=True, need_bias=ctx.with_bias, y_saved=ctx.y_saved)
+        ctx.y_saved = None
         g_in, g_off, g_mask, g_w, g_b = grads
         g_off, g_mask = g_off.to(offset.dtype), g_mask.to(mask.dtype)
         return (g_in, g_off, g_mask, g_w, g_b if ctx.with_bias else None) + (None,) * 5

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from torch.autograd import Function
 
-from .dcn import DeformConv1D, deform_conv_backward, deform_conv_forward
+from .dcn import DeformConv1D, _keep_holder, deform_conv_backward, deform_conv_forward
 
 
 def dcn_base_offset(num_points, dtype=torch.float32, device=None):
@@ -35,8 +35,12 @@ class _FusedLfaTail(Function):
 
     @staticmethod
     def forward(ctx, cls_feat, pts_out_init, weight, stride, padding, dilation, num_points):
+        # float32 training: the per-tap products stay in the forward's workspace for the
+        # backward (they do not depend on the offsets, fused subtraction or not)
+        kept = _keep_holder(ctx, cls_feat, 1)
         out = deform_conv_forward(cls_feat, pts_out_init, weight, stride, padding, dilation,
-                                  1, 1, fuse_relu=True, offset_is_points=True)
+                                  1, 1, fuse_relu=True, offset_is_points=True, keep_y=kept)
+        ctx.y_saved = kept.get("y") if kept is not None else None
         ctx.geometry = (stride, padding, dilation, num_points)
         ctx.save_for_backward(cls_feat, pts_out_init, weight, out)
         return out
@@ -53,7 +57,8 @@ class _FusedLfaTail(Function):
         want = ctx.needs_input_grad
         g_in, g_off, _, g_w, _ = deform_conv_backward(
             cls_feat, offset, weight, grad_pre, stride, padding, dilation, 1, 1,
-            need_input=want[0] or want[1], need_weight=want[2])
+            need_input=want[0] or want[1], need_weight=want[2], y_saved=ctx.y_saved)
+        ctx.y_saved = None
         return g_in, g_off, g_w, None, None, None, None
 
 

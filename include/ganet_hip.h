@@ -112,9 +112,21 @@ typedef struct {
                                3 = algorithm 2 as ONE persistent launch (16-bit
                                arithmetic, Cout <= 64 per tap, "same" output
                                size; opt-in, never chosen automatically:
-                               slower than 2 on MI355X so far) */
+                               slower than 2 on MI355X so far).
+                               | GANET_DCN_ALGO_KEEP_Y: training - see below */
   int32_t debug;            /* must be 0 (ablation bits of profiling builds) */
 } ganet_dcn_params;
+
+/* Added to `algo` (0 or 2) of a FORWARD call: the per-tap products Y = x * W_t^T of the
+ * whole batch, float32 [B][H*W][kH*kW*Cout], are left in the workspace at
+ * ganet_deform_conv_y_offset(p) (one chunk instead of cache-sized ones: the forward gets a
+ * little slower and the workspace holds B*H*W*kH*kW*Cout*4 bytes), for
+ * ganet_deform_conv_backward_y, which then does not form them again.  float32 tensors in the
+ * default arithmetic (mfma_bf16 = 0) where algorithm 2 applies and Cout % 64 == 0;
+ * GANET_ERR_UNSUPPORTED otherwise (call again without the bit).  The reference keeps nothing
+ * between its forward and backward either way (deform_conv.py:52-57, :60-96 recompute the
+ * columns); this is an addition for training throughput. */
+#define GANET_DCN_ALGO_KEEP_Y 0x100
 
 /* Output spatial size rule of the reference
  * (mmdet/ops/dcn/deform_conv.py:98-111, deform_conv_cuda.cpp:108-111). */
@@ -138,6 +150,10 @@ int ganet_deform_conv_algorithm(const ganet_dcn_params *p);
  * algorithm chosen for `p` has no such word.  The word is valid once the stream has
  * finished the call.  No counterpart in the reference (its launches cannot fail this way). */
 size_t ganet_deform_conv_status_offset(const ganet_dcn_params *p);
+
+/* Byte offset of the kept per-tap products inside `workspace` for a forward call with
+ * GANET_DCN_ALGO_KEEP_Y, (size_t)-1 when `p` does not keep them. */
+size_t ganet_deform_conv_y_offset(const ganet_dcn_params *p);
 
 /* Weight pre-packing (no counterpart in the reference, which hands the raw
  * [Cout,Cin,kH,kW] tensor to cuBLAS on every call, deform_conv_cuda.cpp:228-236):
@@ -193,6 +209,19 @@ int ganet_deform_conv_backward(const void *x, const float *offset, const float *
                                void *grad_bias, const ganet_dcn_params *p,
                                void *workspace, size_t workspace_bytes,
                                ganet_stream_t stream);
+
+/* The same backward with the forward's per-tap products handed over (`y_saved` = the
+ * forward's workspace + ganet_deform_conv_y_offset, x / offset / weight unchanged since):
+ * the commuted form skips its own contraction of x (about a sixth of the call at the LFA
+ * shape).  The products are the ones ganet_deform_conv_backward forms itself (the same
+ * three bf16 passes), so the gradients are the same up to the order of the atomic sums.  float32 tensors,
+ * commuted form only (GANET_ERR_UNSUPPORTED otherwise). */
+int ganet_deform_conv_backward_y(const void *x, const float *offset, const float *mask,
+                                 const void *weight, const void *grad_out, void *grad_x,
+                                 float *grad_offset, float *grad_mask, void *grad_weight,
+                                 void *grad_bias, const ganet_dcn_params *p,
+                                 void *workspace, size_t workspace_bytes,
+                                 ganet_stream_t stream, const void *y_saved);
 
 /* ------------------------------------------------------------------------
  * (2) Keypoint decode + lane grouping for a batch of images.

@@ -332,3 +332,105 @@ def test_conv_groups_forward_and_backward(case, modulated):
         m.weight.copy_(tw)
     if not modulated:
         close(m(tx, toff), fref, "DeformConv(groups=%d)" % g)
+
+
+KEPT = [COMMUTED[0], COMMUTED[1], COMMUTED[2], COMMUTED[4]]   # 2*Cout <= Cin: commuted by default
+
+
+@pytest.mark.parametrize("case", KEPT)
+@pytest.mark.parametrize("modulated", [False, True])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_backward_on_the_forwards_products(case, modulated, channels_last):
+    """GANET_DCN_ALGO_KEEP_Y + ganet_deform_conv_backward_y: the forward leaves the per-tap
+    products of the whole batch in its workspace, the backward reads them instead of
+    contracting x again.  Same output, same gradients (the products are formed by the same
+    three bf16 passes; sums through atomics differ in order only), and the oracle's."""
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 21, modulated)
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo = (torch.from_numpy(a).to(dev) for a in (x, off, w, go))
+    tm = torch.from_numpy(mask).to(dev) if modulated else None
+    tb = torch.zeros(Cout, device=dev) if modulated else None
+    if channels_last:
+        tx = tx.contiguous(memory_format=torch.channels_last)
+        tgo = tgo.contiguous(memory_format=torch.channels_last)
+    keep = {}
+    out_k = dcn.deform_conv_forward(tx, toff, tw, st, pad, dil, 1, dg, mask=tm, bias=tb, keep_y=keep)
+    out = dcn.deform_conv_forward(tx, toff, tw, st, pad, dil, 1, dg, mask=tm, bias=tb)
+    assert "y" in keep and keep["y"].numel() == B * H * W * kH * kW * Cout
+    assert torch.equal(out, out_k)
+    with_y = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm,
+                                      need_bias=modulated, y_saved=keep["y"])
+    plain = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg, mask=tm,
+                                     need_bias=modulated)
+    for a, b in zip(with_y, plain):
+        assert (a is None) == (b is None)
+        if a is not None:
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 1e-5 * max(scale, 1e-30)   # order of the atomic sums
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg, mask=mask)
+    close(with_y[0], ref["grad_x"], "grad_x")
+    close(with_y[1], ref["grad_offset"], "grad_offset")
+    close(with_y[3], ref["grad_weight"], "grad_weight")
+    if modulated:
+        close(with_y[2], ref["grad_mask"], "grad_mask")
+
+
+def test_products_are_kept_only_where_the_library_can():
+    dev = torch.device("cuda", 0)
+    # Cout 32 (not a 64-block), bf16 tensors, stride 2: the holder stays empty, the call works
+    for (Cin, Cout, dtype, st) in [(64, 32, torch.float32, (1, 1)), (256, 64, torch.bfloat16, (1, 1)),
+                                   (256, 64, torch.float32, (2, 2))]:
+        x = torch.randn(2, Cin, 8, 12, device=dev).to(dtype)
+        w = torch.randn(Cout, Cin, 1, 7, device=dev).to(dtype) * 0.1
+        Wo = (12 + 6 - 7) // st[1] + 1
+        Ho = (8 - 1) // st[0] + 1
+        off = torch.randn(2, 14, Ho, Wo, device=dev)
+        keep = {}
+        out = dcn.deform_conv_forward(x, off, w, st, (0, 3), (1, 1), keep_y=keep)
+        assert keep == {}
+        assert torch.equal(out, dcn.deform_conv_forward(x, off, w, st, (0, 3), (1, 1)))
+    # the workspace-size limit of the Python layer
+    old = dcn.config.keep_y_max_bytes
+    try:
+        dcn.config.keep_y_max_bytes = 1024
+        x = torch.randn(2, 256, 8, 12, device=dev)
+        w = torch.randn(64, 256, 1, 7, device=dev) * 0.1
+        keep = {}
+        dcn.deform_conv_forward(x, torch.randn(2, 14, 8, 12, device=dev), w, (1, 1), (0, 3), (1, 1),
+                                keep_y=keep)
+        assert keep == {}
+    finally:
+        dcn.config.keep_y_max_bytes = old
+
+
+def test_autograd_keeps_the_products_at_the_lfa_shape():
+    """DeformConv1D at the LFA's channel counts: the autograd path keeps the products by
+    default; gradients against the oracle, and equal to the path with keeping switched off."""
+    case = CASES[5]
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 13, False)
+    dev = torch.device("cuda", 0)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg)
+    grads = []
+    for keep in (True, False):
+        old = dcn.config.keep_y_for_backward
+        dcn.config.keep_y_for_backward = keep
+        try:
+            m = dcn.DeformConv1D(Cin, Cout, kW, stride=1, padding=pad[1], dilation=1).to(dev)
+            with torch.no_grad():
+                m.weight.copy_(torch.from_numpy(w))
+            tx = torch.from_numpy(x).to(dev).requires_grad_(True)
+            toff = torch.from_numpy(off).to(dev).requires_grad_(True)
+            out = m(tx, toff)
+            kept = out.grad_fn.y_saved is not None
+            assert kept == keep
+            out.backward(torch.from_numpy(go).to(dev))
+        finally:
+            dcn.config.keep_y_for_backward = old
+        close(tx.grad, ref["grad_x"], "grad_x")
+        close(toff.grad, ref["grad_offset"], "grad_offset")
+        close(m.weight.grad, ref["grad_weight"], "grad_weight")
+        grads.append((tx.grad, toff.grad, m.weight.grad))
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())

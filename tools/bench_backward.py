@@ -53,10 +53,23 @@ def main():
     t_b = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, (K - 1) // 2), (1, 1),
                                                  need_input=True, need_weight=True,
                                                  algo=args.algo))
+    # the forward keeping its per-tap products, the backward reading them
+    # (GANET_DCN_ALGO_KEEP_Y / ganet_deform_conv_backward_y)
+    keep = {}
+    t_fk = timed(lambda: dcn.deform_conv_forward(tx, toff, tw, (1, 1), (0, (K - 1) // 2), (1, 1),
+                                                 keep_y=keep))
+    t_bk = None
+    if "y" in keep:
+        t_bk = timed(lambda: dcn.deform_conv_backward(tx, toff, tw, go, (1, 1), (0, (K - 1) // 2),
+                                                      (1, 1), need_input=True, need_weight=True,
+                                                      algo=args.algo, y_saved=keep["y"]))
     print(json.dumps(dict(batch=B, hw=[H, W], k=K, channels_last=args.channels_last, algo=args.algo,
                           forward_ms=t_f, backward_input_ms=t_i, backward_weight_ms=t_w,
                           backward_both_ms=t_b,
-                          train_images_per_s=B / ((t_f + t_b) * 1e-3))))
+                          train_images_per_s=B / ((t_f + t_b) * 1e-3),
+                          forward_keep_y_ms=t_fk if "y" in keep else None,
+                          backward_both_with_y_ms=t_bk,
+                          train_images_per_s_with_y=(B / ((t_fk + t_bk) * 1e-3)) if t_bk else None)))
 
 
 if __name__ == "__main__":
