@@ -21,6 +21,7 @@ GANET_ERR_NOT_FINITE = -7
 GANET_F32, GANET_BF16, GANET_F16 = 0, 1, 2
 GANET_NCHW, GANET_NHWC = 0, 1
 GANET_DCN_ALGO_KEEP_Y = 0x100
+GANET_DCN_BWD_OVERWRITE_X = 0x200
 DECODE_MAX_CENTERS = 2048
 DECODE_COUNT_STRIDE = 8
 

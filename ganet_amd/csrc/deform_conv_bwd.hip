@@ -1046,6 +1046,7 @@ struct BwdPlan {
   int nb;                 // images per chunk
   size_t y_bytes, gy_bytes, gxc_bytes, wqt_bytes, wsp_bytes, geo_bytes;
   size_t gb_bytes;   // float32 bias gradient of a 16-bit call
+  bool overwrite_x;  // GANET_DCN_BWD_OVERWRITE_X: grad_x is written, not added into
   size_t total() const {
     return xh_bytes + gxh_bytes + go_bytes + wp_bytes + gwp_bytes + y_bytes + gy_bytes +
            gxc_bytes + wqt_bytes + wsp_bytes + geo_bytes + gb_bytes;
@@ -1055,7 +1056,11 @@ struct BwdPlan {
 int make_bwd_plan(const ganet_dcn_params *p_in, BwdPlan *pl) {
   if (!p_in) return GANET_ERR_NULL;
   ganet_dcn_params q = *p_in;   // the forward's GANET_DCN_ALGO_KEEP_Y bit means nothing here
+  if (q.algo < 0 || (q.algo & ~(0xff | GANET_DCN_ALGO_KEEP_Y | GANET_DCN_BWD_OVERWRITE_X)))
+    return GANET_ERR_BAD_SHAPE;
+  pl->overwrite_x = (q.algo & GANET_DCN_BWD_OVERWRITE_X) != 0;
   q.algo &= 0xff;
+  if (q.algo > 2) return GANET_ERR_BAD_SHAPE;
   const ganet_dcn_params *p = &q;
   if (p->B <= 0 || p->Cin <= 0 || p->H <= 0 || p->W <= 0 || p->Cout <= 0)
     return GANET_ERR_BAD_SHAPE;
@@ -1197,6 +1202,16 @@ int backward_impl(const void *x, const float *offset, const float *mask, const v
     long long b = (n + 255) / 256;
     return (unsigned)(b > 65535 ? 65535 : (b < 1 ? 1 : b));
   };
+
+  // GANET_DCN_BWD_OVERWRITE_X: where the commuted form writes the caller's channel-last
+  // float32 grad_x straight from its GEMM every element is stored exactly once (no zero-fill,
+  // no read of old values); every other path adds, so the tensor is cleared here first
+  const bool direct_gx = pl.commuted && need_in && pl.Cp <= 256 && p->x_layout == GANET_NHWC &&
+                         pl.Cp == p->Cin && p->dtype == GANET_F32;
+  if (pl.overwrite_x && need_in && !direct_gx &&
+      hipMemsetAsync(grad_x, 0, (size_t)npix_in * p->Cin * (p->dtype == GANET_F32 ? 4 : 2), s) !=
+          hipSuccess)
+    return GANET_ERR_HIP;
 
   // channel-last views of x and grad_out
   if (pl.copy_x) {
@@ -1348,13 +1363,12 @@ int backward_impl(const void *x, const float *offset, const float *mask, const v
                            dim3(CS_WAVES * 64), 0, s, c);
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
       }
-      if (need_in && pl.Cp <= 256 && p->x_layout == GANET_NHWC && pl.Cp == p->Cin &&
-          dt == GANET_F32) {
+      if (direct_gx) {
         // grad_x += grad_Y * Wq straight into the caller's channel-last tensor (three bf16
         // passes, K-outer kernel: grad_Y is read once)
         float *gx = static_cast<float *>(grad_x) + (size_t)img0 * HW * p->Cin;
         const int rc2 = cts_gemm_f32_split_wide(gyb, wsp + 2 * (size_t)N * pl.Cp, gx, M, N, pl.Cp,
-                                                p->Cin, 1, s);
+                                                p->Cin, pl.overwrite_x ? 0 : 1, s);
         if (rc2 != GANET_OK) return rc2;
       } else if (need_in) {
         const int rc2 = pl.Cp <= 256

@@ -210,7 +210,7 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
 def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
                          padding=(0, 0), dilation=(1, 1), groups=1, deformable_groups=1,
                          mask=None, need_input=True, need_weight=True, need_bias=False,
-                         algo=0, y_saved=None):
+                         algo=0, y_saved=None, overwrite=True):
     """Raw backward on the HIP library (float32).  Returns
     (grad_input, grad_offset, grad_mask, grad_weight, grad_bias); entries that were not
     asked for (or have no meaning without a mask) are None.  grad_input has the memory
@@ -250,10 +250,12 @@ def deform_conv_backward(input, offset, weight, grad_output, stride=(1, 1),
     p.dtype = _DTYPES[input.dtype]
     p.x_layout = _lib.GANET_NHWC if nhwc else _lib.GANET_NCHW
     p.out_layout = _lib.GANET_NHWC if go_nhwc else _lib.GANET_NCHW
-    p.algo = algo
+    # overwrite: grad_input is written, not added into, and needs no zero-fill here
+    # (GANET_DCN_BWD_OVERWRITE_X); False: the reference's zero-fill-then-add contract
+    p.algo = algo | (_lib.GANET_DCN_BWD_OVERWRITE_X if overwrite else 0)
     grad_input = grad_offset = grad_mask = grad_weight = grad_bias = None
-    if need_input:
-        grad_input = torch.zeros_like(input)       # keeps the memory format
+    if need_input:                                 # both keep the memory format
+        grad_input = torch.empty_like(input) if overwrite else torch.zeros_like(input)
         grad_offset = torch.empty_like(offset)
         if mask is not None:
             grad_mask = torch.empty_like(mask)

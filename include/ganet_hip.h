@@ -128,6 +128,13 @@ typedef struct {
  * columns); this is an addition for training throughput. */
 #define GANET_DCN_ALGO_KEEP_Y 0x100
 
+/* Added to `algo` of a BACKWARD call: grad_x is written instead of added into, so the
+ * caller need not zero-fill it (the reference's Python does, deform_conv.py:73-75, and its
+ * col2im adds).  Where the gradient comes straight out of a GEMM (commuted form, float32
+ * channel-last tensors) this saves the fill and the read of the old values; elsewhere the
+ * library clears the tensor itself.  grad_weight / grad_bias are still added into. */
+#define GANET_DCN_BWD_OVERWRITE_X 0x200
+
 /* Output spatial size rule of the reference
  * (mmdet/ops/dcn/deform_conv.py:98-111, deform_conv_cuda.cpp:108-111). */
 int ganet_dcn_out_size(int in, int pad, int dilation, int k, int stride);

@@ -434,3 +434,29 @@ def test_autograd_keeps_the_products_at_the_lfa_shape():
         grads.append((tx.grad, toff.grad, m.weight.grad))
     for a, b in zip(*grads):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5], COMMUTED[1]])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_grad_x_written_or_added_into(case, channels_last):
+    """GANET_DCN_BWD_OVERWRITE_X (the Python layer's default): grad_x comes back complete in
+    an uninitialised tensor; without the bit the call adds into the caller's zero-filled
+    tensor as the reference does (deform_conv.py:73-75).  Direct and commuted forms, both
+    layouts."""
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, mask, go = make(case, 17, False)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg)
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo = (torch.from_numpy(a).to(dev) for a in (x, off, w, go))
+    if channels_last:
+        tx = tx.contiguous(memory_format=torch.channels_last)
+        tgo = tgo.contiguous(memory_format=torch.channels_last)
+    # poison the allocator's next blocks so that a missing store would show
+    junk = [torch.full_like(tx, float("nan")) for _ in range(3)]
+    del junk
+    for overwrite in (True, False):
+        gi, goff, _, gw, _ = dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg,
+                                                      overwrite=overwrite)
+        close(gi, ref["grad_x"], "grad_x (overwrite=%s)" % overwrite)
+        close(goff, ref["grad_offset"], "grad_offset")
+        close(gw, ref["grad_weight"], "grad_weight")
