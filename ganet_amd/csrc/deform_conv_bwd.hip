@@ -1009,31 +1009,35 @@ bool launch_wgrad_split(const float *gy, const float *x, float *gw, long long M,
   return true;
 }
 
-// float32 matrix -> a high and a low bf16 plane (v = hi + lo up to 2^-18 |v|), the operand
-// form of cts_gemm_split_kernel
-__global__ __launch_bounds__(256) void bwd_split_rows_kernel(const float *__restrict__ src,
-                                                             unsigned short *__restrict__ dst,
-                                                             long long n) {
-  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n;
-       k += (long long)gridDim.x * 256) {
-    const float v = src[k];
-    const __bf16 hi = (__bf16)v;
-    const float hf = __uint_as_float(((unsigned)__builtin_bit_cast(unsigned short, hi)) << 16);
-    const __bf16 lo = (__bf16)(v - hf);
-    dst[k] = __builtin_bit_cast(unsigned short, hi);
-    dst[n + k] = __builtin_bit_cast(unsigned short, lo);
-  }
-}
-
-// dst[c][n] = src[n][c]
-__global__ __launch_bounds__(256) void bwd_transpose_kernel(const float *__restrict__ src,
-                                                            float *__restrict__ dst, int N,
-                                                            int Cp) {
+// The commuted form's weight views in one launch (they were four: pack, transpose, two
+// splits, ~5 us each of launch latency): wp[n][c] float32, its transpose wqt[c][n], and the
+// high / low bf16 planes of both (wsp: hi[n][c], lo[n][c], hi[c][n], lo[c][n]).
+template <typename TS>
+__global__ __launch_bounds__(256) void bwd_weight_views_kernel(
+    const TS *__restrict__ w, float *__restrict__ wp, float *__restrict__ wqt,
+    unsigned short *__restrict__ wsp, int Cout, int Cin, int T, int Cp, int groups) {
+  const int cig = Cin / groups, cog = Cout / groups;
+  const int N = T * Cout;
   const long long total = (long long)N * Cp;
   for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
        k += (long long)gridDim.x * 256) {
-    const int c = (int)(k / N), n = (int)(k - (long long)c * N);
-    dst[k] = src[(size_t)n * Cp + c];
+    const int cc = (int)(k % Cp);
+    const int n = (int)(k / Cp);
+    const int o = n % Cout, t = n / Cout;
+    const int cg = cc - (o / cog) * cig;
+    const float v = (cc < Cin && cg >= 0 && cg < cig) ? to_f32(w[((size_t)o * cig + cg) * T + t]) : 0.f;
+    const __bf16 hi = (__bf16)v;
+    const float hf = __uint_as_float(((unsigned)__builtin_bit_cast(unsigned short, hi)) << 16);
+    const __bf16 lo = (__bf16)(v - hf);
+    const unsigned short uh = __builtin_bit_cast(unsigned short, hi);
+    const unsigned short ul = __builtin_bit_cast(unsigned short, lo);
+    const long long kt = (long long)cc * N + n;
+    wp[k] = v;
+    wqt[kt] = v;
+    wsp[k] = uh;
+    wsp[total + k] = ul;
+    wsp[2 * total + kt] = uh;
+    wsp[3 * total + kt] = ul;
   }
 }
 
@@ -1282,16 +1286,10 @@ int backward_impl(const void *x, const float *offset, const float *mask, const v
     unsigned char *geo = cw + pl.y_bytes + pl.gy_bytes + pl.gxc_bytes + pl.wqt_bytes + pl.wsp_bytes;
     const int N = T * p->Cout;
     if (need_in) {
-      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_pack_weight_kernel<TIO>,
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_weight_views_kernel<TIO>,
                                                dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
-                                               s, static_cast<const TIO *>(weight), wp, p->Cout,
-                                               p->Cin, T, pl.Cp, p->groups));
-      hipLaunchKernelGGL(bwd_transpose_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
-                         s, wp, wqt, N, pl.Cp);
-      hipLaunchKernelGGL(bwd_split_rows_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
-                         s, wp, wsp, (long long)N * pl.Cp);
-      hipLaunchKernelGGL(bwd_split_rows_kernel, dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0,
-                         s, wqt, wsp + 2 * (size_t)N * pl.Cp, (long long)N * pl.Cp);
+                                               s, static_cast<const TIO *>(weight), wp, wqt, wsp,
+                                               p->Cout, p->Cin, T, pl.Cp, p->groups));
       if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
       const size_t off_elems = (size_t)p->B * 2 * T * HWo;
       if (hipMemsetAsync(grad_offset, 0, off_elems * 4, s) != hipSuccess) return GANET_ERR_HIP;
