@@ -126,6 +126,45 @@ def test_algorithm_choice_is_host_logic():
     assert L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(strided)) == 0
 
 
+def test_algo_bits_are_host_logic():
+    """GANET_DCN_ALGO_KEEP_Y / GANET_DCN_BWD_OVERWRITE_X ride on `algo`: where the per-tap
+    products can be kept the workspace grows to the whole batch's Y and the offset is
+    reported; elsewhere the offset is -1 and the forward call refuses the bit."""
+    L = _lib.lib()
+    none = ctypes.c_size_t(-1).value
+    B, H, W, T, Cout = 48, 40, 100, 7, 64
+    lfa = dict(B=B, Cin=256, H=H, W=W, Cout=Cout, x_layout=1, out_layout=1)
+    plain = _dcn_params(**lfa)
+    keep = _dcn_params(algo=_lib.GANET_DCN_ALGO_KEEP_Y, **lfa)
+    assert L.ganet_deform_conv_y_offset(ctypes.byref(plain)) == none
+    assert L.ganet_deform_conv_y_offset(ctypes.byref(keep)) == 0      # channel-last x: no copy in front
+    y_bytes = B * H * W * T * Cout * 4
+    wk = L.ganet_deform_conv_workspace_bytes(ctypes.byref(keep))
+    wp = L.ganet_deform_conv_workspace_bytes(ctypes.byref(plain))
+    assert wk >= y_bytes > 144 << 20 and wp < wk                      # one chunk instead of cache-sized ones
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(keep)) == 2
+    nchw = _dcn_params(algo=2 | _lib.GANET_DCN_ALGO_KEEP_Y, **dict(lfa, x_layout=0, out_layout=0))
+    assert L.ganet_deform_conv_y_offset(ctypes.byref(nchw)) == B * 256 * H * W * 4
+    fake = ctypes.c_void_p(256)
+    for kw in (dict(dtype=_lib.GANET_BF16), dict(Cout=32), dict(sW=2), dict(mfma_bf16=1),
+               dict(algo=1 | _lib.GANET_DCN_ALGO_KEEP_Y), dict(algo=3 | _lib.GANET_DCN_ALGO_KEEP_Y)):
+        q = _dcn_params(**dict(dict(lfa, algo=_lib.GANET_DCN_ALGO_KEEP_Y), **kw))
+        assert L.ganet_deform_conv_y_offset(ctypes.byref(q)) == none, kw
+        rc = L.ganet_deform_conv_forward(fake, fake, None, fake, None, fake, ctypes.byref(q),
+                                         fake, 1 << 40, None)
+        assert rc == _lib.GANET_ERR_UNSUPPORTED, (kw, rc)
+    bad = _dcn_params(algo=0x400, **lfa)
+    assert L.ganet_deform_conv_workspace_bytes(ctypes.byref(bad)) == 0
+    # the backward ignores the forward's bit, takes its own, refuses unknown ones
+    b0 = _dcn_params(**lfa)
+    b1 = _dcn_params(algo=_lib.GANET_DCN_ALGO_KEEP_Y | _lib.GANET_DCN_BWD_OVERWRITE_X, **lfa)
+    w0 = L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(b0))
+    assert w0 > 0 and L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(b1)) == w0
+    assert L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(bad)) == 0
+    assert L.ganet_deform_conv_backward_y(fake, fake, None, fake, fake, fake, fake, None, fake, None,
+                                          ctypes.byref(b0), fake, 1 << 40, None, None) == _lib.GANET_ERR_NULL
+
+
 def test_decode_validation_without_gpu():
     L = _lib.lib()
     p = _lib.DecodeParams()
