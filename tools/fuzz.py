@@ -215,16 +215,66 @@ def fuzz_decode(rng, n):
     return bad
 
 
+def fuzz_lfa(rng, n):
+    """LFA-shaped problems at sizes that walk the batched kernels: several chunks, ragged
+    tiles, every algorithm that applies, the fused offset subtraction."""
+    bad = 0
+    for i in range(n):
+        Cin = int(rng.choice([64, 128, 256]))
+        Cout = int(rng.choice([64, 64, 128])) if Cin == 256 else 64
+        K = int(rng.choice([5, 7, 9]))
+        H, W, B = int(rng.integers(5, 48)), int(rng.integers(5, 110)), int(rng.integers(1, 40))
+        dtype = [torch.float32, torch.bfloat16, torch.bfloat16, torch.float16][int(rng.integers(0, 4))]
+        algos = [0, 1] + ([2] if 2 * Cout <= Cin else []) + \
+            ([3] if 2 * Cout <= Cin and Cout == 64 and dtype != torch.float32 else [])
+        algo = int(rng.choice(algos))
+        nhwc, relu, points = rng.random() < 0.7, rng.random() < 0.5, rng.random() < 0.5
+        x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+        w = (rng.standard_normal((Cout, Cin, 1, K)) / np.sqrt(Cin * K)).astype(np.float32)
+        off = (rng.standard_normal((B, 2 * K, H, W)) * float(rng.choice([0.5, 1.5, 6.0]))).astype(np.float32)
+        base = np.zeros((1, 2 * K, 1, 1), np.float32)
+        base[0, 1::2, 0, 0] = np.arange(-(K - 1) // 2, (K - 1) // 2 + 1)
+        tx = torch.from_numpy(x).to(DEV).to(dtype)
+        tw = torch.from_numpy(w).to(DEV).to(dtype)
+        if nhwc:
+            tx = tx.contiguous(memory_format=torch.channels_last)
+        tag = "lfa %3d B=%d Cin=%d Cout=%d K=%d %dx%d dtype=%s nhwc=%d relu=%d points=%d algo=%d" % (
+            i, B, Cin, Cout, K, H, W, str(dtype).split(".")[1], nhwc, relu, points, algo)
+        given = off + base if points else off
+        try:
+            out = dcn.deform_conv_forward(tx, torch.from_numpy(given).to(DEV), tw, (1, 1),
+                                          (0, (K - 1) // 2), (1, 1), fuse_relu=relu,
+                                          offset_is_points=points, algo=algo, check=True)
+        except Exception as e:  # noqa: BLE001
+            print("FAIL (%r) %s" % (e, tag))
+            bad += 1
+            continue
+        ref = O.deform_conv_forward(tx.float().cpu().numpy(), off, tw.float().cpu().numpy(), (1, 1),
+                                    (0, (K - 1) // 2), (1, 1), nthreads=16)
+        if relu:
+            ref = np.maximum(ref, 0)
+        got = out.float().cpu().numpy()
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        err = float(np.abs(got - ref).max()) / scale
+        if not np.isfinite(got).all() or err > TOL[dtype]:
+            print("FAIL (err %.3g) %s" % (err, tag))
+            bad += 1
+    print("lfa: %d cases, %d failed" % (n, bad), flush=True)
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--forward", type=int, default=100)
     ap.add_argument("--backward", type=int, default=50)
     ap.add_argument("--decode", type=int, default=100)
+    ap.add_argument("--lfa", type=int, default=0)
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
-    bad = fuzz_forward(rng, args.forward) + fuzz_backward(rng, args.backward) + fuzz_decode(rng, args.decode)
+    bad = fuzz_forward(rng, args.forward) + fuzz_backward(rng, args.backward) + \
+        fuzz_decode(rng, args.decode) + fuzz_lfa(rng, args.lfa)
     print("fuzz seed %d: %d failures in %.0f s" % (args.seed, bad, time.time() - t0))
     raise SystemExit(1 if bad else 0)
 
