@@ -223,7 +223,7 @@ def fuzz_lfa(rng, n):
         Cin = int(rng.choice([64, 128, 256]))
         Cout = int(rng.choice([64, 64, 128])) if Cin == 256 else 64
         K = int(rng.choice([5, 7, 9]))
-        H, W, B = int(rng.integers(5, 48)), int(rng.integers(5, 110)), int(rng.integers(1, 40))
+        H, W, B = int(rng.integers(1, 48)), int(rng.integers(K, 110)), int(rng.integers(1, 40))   # W >= K: the reference refuses narrower maps
         dtype = [torch.float32, torch.bfloat16, torch.bfloat16, torch.float16][int(rng.integers(0, 4))]
         algos = [0, 1] + ([2] if 2 * Cout <= Cin else []) + \
             ([3] if 2 * Cout <= Cin and Cout == 64 and dtype != torch.float32 else [])
