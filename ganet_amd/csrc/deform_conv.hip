@@ -634,13 +634,14 @@ int make_plan(const ganet_dcn_params *p_in, Plan *pl) {
   if ((p->x_layout != GANET_NCHW && p->x_layout != GANET_NHWC) ||
       (p->out_layout != GANET_NCHW && p->out_layout != GANET_NHWC))
     return GANET_ERR_BAD_SHAPE;
+  if (!ganet_dcn_ranges_ok(p)) return GANET_ERR_UNSUPPORTED;
   pl->Ho = ganet_dcn_out_size(p->H, p->pH, p->dH, p->kH, p->sH);
   pl->Wo = ganet_dcn_out_size(p->W, p->pW, p->dW, p->kW, p->sW);
   if (pl->Ho < 1 || pl->Wo < 1) return GANET_ERR_TOO_SMALL;
   if (p->offset_is_points &&
       (p->kH != 1 || p->dW != 1 || p->pW != (p->kW - 1) / 2 || !(p->kW & 1)))
     return GANET_ERR_BAD_SHAPE;
-  if ((long long)p->B * p->H * p->W >= (1ll << 31) ||
+  if ((long long)p->B * pl->Ho >= (1ll << 31) ||
       (long long)p->B * pl->Ho * pl->Wo >= (1ll << 31))
     return GANET_ERR_UNSUPPORTED;
   pl->T = p->kH * p->kW;
@@ -770,9 +771,11 @@ void launch_main(const Plan &pl, const DcnArgs &a, hipStream_t s) {
 extern "C" int ganet_dcn_out_size(int in, int pad, int dilation, int k,
                                   int stride) {
   if (stride <= 0) return 0;
-  const int num = in + 2 * pad - (dilation * (k - 1) + 1);
+  // 64-bit: any int32 arguments are a defined computation (the reference computes in Python)
+  const long long num = (long long)in + 2ll * pad - ((long long)dilation * ((long long)k - 1) + 1);
   if (num < 0) return 0;  // Python floor division would give <= 0 here
-  return num / stride + 1;
+  const long long out = num / stride + 1;
+  return out > 0x7fffffffll ? 0 : (int)out;
 }
 
 extern "C" size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p) {

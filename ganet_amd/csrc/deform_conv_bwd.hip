@@ -1081,6 +1081,7 @@ int make_bwd_plan(const ganet_dcn_params *p_in, BwdPlan *pl) {
   // workspace, the gradients are formed in float32 and rounded once on the way out
   const bool io16 = p->dtype != GANET_F32;
   if (p->offset_is_points || p->fuse_relu || p->weight_is_packed) return GANET_ERR_UNSUPPORTED;
+  if (!ganet_dcn_ranges_ok(p)) return GANET_ERR_UNSUPPORTED;
   pl->Ho = ganet_dcn_out_size(p->H, p->pH, p->dH, p->kH, p->sH);
   pl->Wo = ganet_dcn_out_size(p->W, p->pW, p->dW, p->kW, p->sW);
   if (pl->Ho < 1 || pl->Wo < 1) return GANET_ERR_BAD_SHAPE;
@@ -1090,6 +1091,7 @@ int make_bwd_plan(const ganet_dcn_params *p_in, BwdPlan *pl) {
   if (dg > 1 && (p->Cin / dg) % 32) return GANET_ERR_UNSUPPORTED;
   pl->Cp = (p->Cin + 31) / 32 * 32;
   const size_t npix_in = (size_t)p->B * p->H * p->W;
+  if ((long long)p->B * pl->Ho >= (1ll << 31)) return GANET_ERR_UNSUPPORTED;
   const size_t npix_out = (size_t)p->B * pl->Ho * pl->Wo;
   if (npix_in * pl->Cp >= 0x7fffffffull || npix_out >= 0x7fffffffull)
     return GANET_ERR_UNSUPPORTED;  // 32-bit row indices in the sample table

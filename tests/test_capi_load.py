@@ -165,6 +165,26 @@ def test_algo_bits_are_host_logic():
                                           ctypes.byref(b0), fake, 1 << 40, None, None) == _lib.GANET_ERR_NULL
 
 
+def test_extreme_parameters_are_refused_not_overflowed():
+    """Sizes whose products would overflow the host arithmetic are refused on the host
+    (tools/asan_plan.sh runs the same queries under UBSan with 400 000 random parameter sets)."""
+    L = _lib.lib()
+    big = 0x7fffffff
+    assert L.ganet_dcn_out_size(big, big, 1, 1, 1) == 0          # result beyond int32
+    assert L.ganet_dcn_out_size(10, 0, big, big, 1) == 0
+    assert L.ganet_dcn_out_size(big, 0, 1, 1, 1) == big
+    fake = ctypes.c_void_p(256)
+    for kw in (dict(B=big, H=big, W=big), dict(kH=big, kW=big), dict(kW=8192, pW=4096, W=20000),
+               dict(pW=big), dict(Cin=1 << 24, Cout=1 << 24), dict(dW=big), dict(sW=big)):
+        q = _dcn_params(**kw)
+        assert L.ganet_deform_conv_workspace_bytes(ctypes.byref(q)) == 0, kw
+        assert L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(q)) == 0, kw
+        rc = L.ganet_deform_conv_forward(fake, fake, None, fake, None, fake, ctypes.byref(q),
+                                         fake, 1 << 40, None)
+        assert rc in (_lib.GANET_ERR_UNSUPPORTED, _lib.GANET_ERR_BAD_SHAPE,
+                      _lib.GANET_ERR_TOO_SMALL), (kw, rc)
+
+
 def test_decode_validation_without_gpu():
     L = _lib.lib()
     p = _lib.DecodeParams()
