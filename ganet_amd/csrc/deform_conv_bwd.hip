@@ -848,22 +848,26 @@ __global__ __launch_bounds__(256) void cts_bwd_wgrad_kernel(const float *__restr
 
 // The same product on the bf16 matrix cores in three passes over high/low splits (the
 // float32 MFMA runs at the vector rate, and 64 x 64 blocks re-read gy and x 4 + 7 times).
-// One workgroup of 8 wavefronts owns 2*NTW*32 rows (n) x 128 columns (c) of gw and a share
-// of the pixels; wavefront w keeps NTW 32 x 32 accumulators (c tile w & 3, n half w >> 2).
+// One workgroup of 8 wavefronts owns NH*NTW*32 rows (n) x (8/NH)*32 columns (c) of gw and a
+// share of the pixels; wavefront w keeps NTW 32 x 32 accumulators (c tile w % (8/NH), n part
+// w / (8/NH)).  NH = 2: 2*NTW*32 x 128 (gy is read Cp/128 times, x N/(2*NTW*32) times);
+// NH = 1: NTW*32 x 256 (gy Cp/256 times, x N/(NTW*32) times) - at the LFA's 448 x 256 that is
+// gy once + x twice (491 MB for 32 images) instead of gy twice + x once (589 MB).
 // K = pixels, 16 per step: 288 threads each fetch 8 pixels x 4 columns of gy or x as float32
 // (whole 16-byte loads, a pixel row contiguous across lanes), split them, and park them in
 // LDS pixel-major per column ([plane][k half][column][8 pixels] bf16: the 16 bytes a lane
 // reads are one MFMA operand, 32 lanes read 512 contiguous bytes); two buffers, one barrier
 // per step.  One atomic flush of 128-byte runs at the end.
 constexpr int WG_WAVES = 8;
-constexpr int WG_BC = 128;
 constexpr int WG_KS = 16;
 
-template <int NTW>
+template <int NTW, int NH>
 __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
     const float *__restrict__ gy, const float *__restrict__ x, float *__restrict__ gw,
     long long M, int N, int Cp) {
-  constexpr int BN = 2 * NTW * 32;
+  constexpr int BN = NH * NTW * 32;
+  constexpr int CT = WG_WAVES / NH;             // c tiles of 32 per workgroup
+  constexpr int WG_BC = CT * 32;
   constexpr int NCOLS = BN + WG_BC;
   constexpr int NQ = NCOLS / 4;                 // column quads
   constexpr int HALF = NCOLS * 16;              // bytes of one k half of one plane
@@ -877,7 +881,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
   const int ncb = Cp / WG_BC;
   const int bn = blockIdx.x / ncb, bc = blockIdx.x - bn * ncb;
   const int nb0 = bn * BN, cb0 = bc * WG_BC;
-  const int ct = wid & 3, nh = wid >> 2;
+  const int ct = wid % CT, nh = wid / CT;
 
   const long long nks = (M + WG_KS - 1) / WG_KS;
   const long long per = (nks + gridDim.y - 1) / gridDim.y;
@@ -982,8 +986,11 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
 bool launch_wgrad_split(const float *gy, const float *x, float *gw, long long M, int N, int Cp,
                         hipStream_t s) {
   if (getenv("GANET_BWD_WGRAD_F32")) return false;   // A/B knob
-  if (N % 64 || Cp % WG_BC || M < 1) return false;
-  const int m = N / 64;
+  if (N % 64 || Cp % 128 || M < 1) return false;
+  // tall tiles (NH = 1: NTW*32 rows x 256 columns) where gy is the wider matrix and the shape
+  // allows: gy is then read once per 256 columns of x instead of once per 128
+  const bool tall = Cp % 256 == 0 && N >= Cp && !getenv("GANET_BWD_WGRAD_WIDE");
+  const int m = tall ? N / 32 : N / 64;           // row blocks of 32 (tall) or 64 (two halves)
   int ntw = 0;
   for (int cand : {7, 9, 5, 4, 3, 2, 1})
     if (m % cand == 0) {
@@ -991,21 +998,34 @@ bool launch_wgrad_split(const float *gy, const float *x, float *gw, long long M,
       break;
     }
   if (!ntw) return false;
-  const int gx = (m / ntw) * (Cp / WG_BC);
+  const int gx = (m / ntw) * (Cp / (tall ? 256 : 128));
   const long long nks = (M + WG_KS - 1) / WG_KS;
   long long split = 256 / gx;                       // one workgroup per CU
   if (split > nks / 8) split = nks / 8;             // >= 8 steps between flushes
   if (split < 1) split = 1;
   const dim3 grid((unsigned)gx, (unsigned)split), block(WG_WAVES * 64);
+#define GANET_WGRAD_CASE(n)                                                                       \
+  case n:                                                                                         \
+    if (tall)                                                                                     \
+      hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<n, 1>), grid, block, 0, s, gy, x, gw, M, N, Cp); \
+    else                                                                                          \
+      hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<n, 2>), grid, block, 0, s, gy, x, gw, M, N, Cp); \
+    break;
   switch (ntw) {
-    case 1: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<1>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
-    case 2: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<2>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
-    case 3: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<3>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
-    case 4: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<4>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
-    case 5: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<5>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
-    case 7: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<7>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
-    default: hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<9>), grid, block, 0, s, gy, x, gw, M, N, Cp); break;
+    GANET_WGRAD_CASE(1)
+    GANET_WGRAD_CASE(2)
+    GANET_WGRAD_CASE(3)
+    GANET_WGRAD_CASE(4)
+    GANET_WGRAD_CASE(5)
+    GANET_WGRAD_CASE(7)
+    default:
+      if (tall)
+        hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<9, 1>), grid, block, 0, s, gy, x, gw, M, N, Cp);
+      else
+        hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<9, 2>), grid, block, 0, s, gy, x, gw, M, N, Cp);
+      break;
   }
+#undef GANET_WGRAD_CASE
   return true;
 }
 
