@@ -8,8 +8,11 @@ contract and the same Python structures / numeric types:
 The grouping itself (group_points_fast, post_process.py:141-194) runs on the
 GPU (csrc/decode.hip); this file only formats its result
 (lane_post_process, post_process.py:216-242).  The dict-seed `group_points`
-path (group_fast=False) is out of scope, as every shipped config sets
-group_fast=True (configs/*/test_common_s*.py:7).
+path (group_fast=False) is out of scope: every shipped config sets
+group_fast=True (configs/*/test_common_s*.py:7), and the path cannot run in the
+reference either - group_points reads item['align'] / ['score'] / ['center']
+(post_process.py:128) while the decode that would feed it returns tuples
+(ganet_head.py:191), on a multi-offset branch no shipped head takes (:302).
 """
 import numpy as np
 
