@@ -123,7 +123,7 @@ bool cts_applicable(const ganet_dcn_params *p, int Cp, int CoutP);
 // a high and a low bf16 plane)
 bool cts_split(const ganet_dcn_params *p, int Cp);
 // images per chunk (Y of a chunk stays inside the Infinity Cache); Y bytes of nb images
-int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta);
+int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta, bool split);
 size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta, int nb);
 int cts_forward(const void *xh, const float *offset, const float *mask, const void *wq,
                 const void *bias, void *out, const ganet_dcn_params *p, int ta, int kc,

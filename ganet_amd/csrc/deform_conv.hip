@@ -698,7 +698,7 @@ int make_plan(const ganet_dcn_params *p_in, Plan *pl) {
   if (keep_y && (!pl->split || pl->stream || p->Cout % 64)) return GANET_ERR_UNSUPPORTED;
   pl->nb = 0;
   if (pl->cts && !pl->stream) {
-    pl->nb = keep_y ? p->B : cts_chunk_images(p, pl->CoutP, pl->ta);
+    pl->nb = keep_y ? p->B : cts_chunk_images(p, pl->CoutP, pl->ta, pl->split);
     const unsigned long long img_y = (unsigned long long)p->H * p->W * pl->T * pl->CoutP *
                                      dtype_size(pl->ta);
     if (img_y * (unsigned long long)pl->nb >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;

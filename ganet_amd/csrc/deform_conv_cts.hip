@@ -1196,18 +1196,45 @@ bool cts_applicable(const ganet_dcn_params *p, int Cp, int CoutP) {
          p->sH == 1 && p->sW == 1 && p->kH * p->kW <= 64;
 }
 
-// images per chunk: Y of one chunk stays well inside the 256 MiB Infinity Cache, and
-// the chunks are balanced so that no launch is left with a sliver of the batch
-int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta) {
+// images per chunk: Y of one chunk stays well inside the 256 MiB Infinity Cache, the chunks
+// are balanced so that no launch is left with a sliver of the batch, and their number is
+// chosen for whole rounds of GEMM tiles over the 256 CUs: a chunk of 282 tiles costs a second
+// round for 26 of them (C4 at 9 images per chunk: 1.62 ms against 1.40 at 8 = 250 tiles,
+// profiles/r02_algo3_notes.txt).  `split`: float32 tensors on the three-pass GEMM.
+int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta, bool split) {
   const size_t es = ta == GANET_F32 ? 4 : 2;
-  const size_t per_img = (size_t)p->H * p->W * p->kH * p->kW * CoutP * es;
+  const size_t hw = (size_t)p->H * p->W;
+  const size_t per_img = hw * p->kH * p->kW * CoutP * es;
   size_t budget = 144ull << 20;
   if (const char *e = getenv("GANET_CTS_BUDGET_MB")) budget = (size_t)atoi(e) << 20;
   size_t nmax = budget / (per_img ? per_img : 1);
   if (nmax < 1) nmax = 1;
   if (nmax > (size_t)p->B) nmax = p->B;
-  const size_t chunks = ((size_t)p->B + nmax - 1) / nmax;
-  return (int)(((size_t)p->B + chunks - 1) / chunks);
+  const size_t B = (size_t)p->B;
+  const size_t cmin = (B + nmax - 1) / nmax;
+  // rounds of one chunk of n images: tiles of 512 pixels (two row blocks per wavefront) once
+  // that fills the chip, 256 otherwise and on the three-pass kernel (launch_gemm*)
+  auto rounds = [&](size_t n) {
+    const size_t m = n * hw;
+    const size_t rows = (!split && m >= 192ull * GEMM_WAVES * 64) ? GEMM_WAVES * 64 : GEMM_WAVES * 32;
+    const size_t tiles = (m + rows - 1) / rows;
+    return (tiles + 255) / 256;
+  };
+  size_t best_nb = (B + cmin - 1) / cmin;
+  double best_cost = -1.0;
+  const size_t cmax = 2 * cmin + 2 < B ? 2 * cmin + 2 : B;
+  for (size_t c = cmin; c <= cmax; ++c) {
+    const size_t nb = (B + c - 1) / c;
+    const size_t full = B / nb, rest = B - full * nb;
+    // a launch pair costs about a quarter of a round on top of its rounds
+    const double cost = (double)(full * rounds(nb) + (rest ? rounds(rest) : 0)) +
+                        0.25 * (double)(full + (rest ? 1 : 0));
+    if (best_cost < 0 || cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best_nb = nb;
+    }
+  }
+  return (int)best_nb;
 }
 
 size_t cts_y_bytes(const ganet_dcn_params *p, int CoutP, int ta, int nb) {
