@@ -17,6 +17,7 @@ import torch  # noqa: E402
 
 from ganet_amd import _lib, dcn  # noqa: E402
 from ganet_amd import decode as D  # noqa: E402
+from ganet_amd import formats as F  # noqa: E402
 from oracle import cpu_oracle as O  # noqa: E402
 
 DEV = torch.device("cuda", 0)
@@ -198,6 +199,39 @@ def fuzz_decode(rng, n):
             print("FAIL (%r) %s" % (e, tag))
             bad += 1
             continue
+        # the same decode fed with logits (flags bit 3) against torch's own sigmoid + clamp
+        if rng.random() < 0.3:
+            lg = torch.from_numpy((rng.standard_normal((B, 1, H, W)) * 3).astype(np.float32)).to(DEV)
+            pr = torch.clamp(lg.sigmoid(), min=1e-4, max=1 - 1e-4)
+            kw = dict(thr=thr, root_thr=root_thr, cluster_thr=T,
+                      cluster_by_center_thr=T if by_center else None)
+            try:
+                r1 = D.decode_batch(lg, torch.from_numpy(off).to(DEV), torch.from_numpy(err).to(DEV),
+                                    logits=True, **kw)
+                r2 = D.decode_batch(pr, torch.from_numpy(off).to(DEV), torch.from_numpy(err).to(DEV), **kw)
+                if not (np.array_equal(r1.header[:, :3], r2.header[:, :3])
+                        and np.array_equal(r1.records, r2.records)):
+                    print("FAIL (logits) %s" % tag)
+                    bad += 1
+            except RuntimeError as e:
+                if "exceed the device limit" not in str(e):
+                    print("FAIL (logits %r) %s" % (e, tag))
+                    bad += 1
+        # the C++ host formatting against its per-image Python mirror
+        if by_center and rng.random() < 0.5:
+            crop = (0, int(rng.integers(0, 300)), int(rng.integers(800, 1700)), int(rng.integers(400, 800)))
+            shape, pthr, ds = (H * 8, W * 8, 3), int(rng.integers(0, 5)), int(rng.choice([4, 8]))
+            try:
+                bl = F.format_batch(res.packed(), B, True, ds, crop, shape, pthr, threads=int(rng.integers(1, 5)))
+                txt = bl.culane_texts()
+                for b in range(B):
+                    ref_l = F.image_lanes(res.image(b), ds, crop, shape, pthr)
+                    if bl.image(b) != ref_l or txt[b] != F.culane_lines_text(ref_l[0]):
+                        print("FAIL (formats, image %d) %s" % (b, tag))
+                        bad += 1
+                        break
+            except (ValueError, OverflowError):
+                pass     # a non-finite coordinate: both sides refuse (checked in tests/test_formats.py)
         for b in range(B):
             c, kxy, al, rt = O.decode(heat[b], off[b], err[b], thr, root_thr, nms_rows=3 if nms3 else 1)
             gid, means, cgid, ng = O.group_fast(c, rt, T, T if by_center else None, nearest=nearest)
