@@ -428,6 +428,8 @@ def main():
         graph.replay()
         torch.cuda.synchronize()
     if wl["decode"]:
+        if hp.last is None:      # --spinup 0 --warmup 0: the capacity check needs one result
+            one_step()
         over = int(np.bitwise_or.reduce(hp.result().counts[:, 3]))
         if over:
             raise SystemExit("decode capacity overflow in the bench configuration")
@@ -450,6 +452,15 @@ def main():
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)]
               if i % max(1, args.event_every) == 0 else None for i in range(args.steps)]
     consumed = [0, 0]
+    # the host side is warmed like the device side: worker threads started, the formatting
+    # module imported and its first calls (buffer growth, ctypes thunks) made on a warm-up
+    # step's records, all before the timed region (a 20-step run would otherwise time them)
+    pool = None
+    if args.consume:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=args.consume_threads)
+        for fut in [pool.submit(consume, hp.last) for _ in range(2 * args.consume_threads)]:
+            fut.result()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -457,10 +468,7 @@ def main():
     # --consume: two host threads format finished steps while this one enqueues the next
     # (the library calls release the GIL); the result blocks are used in turn, so step
     # i + result_blocks is enqueued only after step i has been formatted
-    pool, pending = None, {}
-    if args.consume:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=args.consume_threads)
+    pending = {}
     for i in range(args.steps):
         if pool is not None and hp.cur in pending:
             nl, nb = pending.pop(hp.cur).result()
