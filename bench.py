@@ -440,11 +440,17 @@ def main():
     fmt_crop, fmt_shape, fmt_thr = (0, 270, 1640, 590), (8 * H if cfg["ds"] == 8 else 4 * H,
                                                          8 * W if cfg["ds"] == 8 else 4 * W), 4
 
+    import threading
+    fmt_local = threading.local()     # every formatting thread keeps its own output buffers
+
     def consume(slot):
         from ganet_amd import formats
+        scratch = getattr(fmt_local, "scratch", None)
+        if scratch is None:
+            scratch = fmt_local.scratch = {}
         bl = formats.format_batch(hp.records(slot), B, True, cfg["ds"], fmt_crop, fmt_shape,
-                                  fmt_thr, threads=fmt_threads)
-        buf, start, length = bl.culane_text_buffer()
+                                  fmt_thr, threads=fmt_threads, scratch=scratch)
+        buf, start, length = bl.culane_text_buffer(scratch=scratch)
         return int(bl.n_lanes().sum()), int(length.sum())
 
     if graph is not None or not wl["decode"]:

@@ -241,16 +241,28 @@ class BatchLanes(object):
                                 raw_file=raw_files[b], run_time=run_time))
                 for b in range(self.B)]
 
-    def culane_text_buffer(self):
+    def culane_text_buffer(self, scratch=None):
         """The `.lines.txt` texts of the batch in one buffer: (bytes-like uint8 array,
-        start [B], length [B]); image b's text is buf[start[b]:start[b] + length[b]]."""
+        start [B], length [B]); image b's text is buf[start[b]:start[b] + length[b]].
+        scratch: a dict the caller keeps between calls (one per thread); the text buffer in it
+        is reused while it is large enough, which saves the size query and the allocation -
+        the returned buffer is then only valid until the next call with the same dict."""
         L = _lib.lib()
         start = np.zeros(2 * self.B + 1, np.uint64)
-        L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads, None, 0,
-                            start.ctypes.data)
-        buf = np.empty(max(int(start[self.B]), 1), np.uint8)
-        rc = L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads, buf.ctypes.data,
-                                 buf.size, start.ctypes.data)
+        buf = scratch.get("text") if scratch is not None else None
+        rc = _lib.GANET_ERR_WORKSPACE
+        if buf is not None:
+            rc = L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads,
+                                     buf.ctypes.data, buf.size, start.ctypes.data)
+        if rc == _lib.GANET_ERR_WORKSPACE:
+            L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads, None, 0,
+                                start.ctypes.data)
+            need = max(int(start[self.B]), 1)
+            buf = np.empty(need if scratch is None else need + need // 4, np.uint8)
+            if scratch is not None:
+                scratch["text"] = buf
+            rc = L.ganet_culane_text(self.stream.ctypes.data, self.B, self.threads,
+                                     buf.ctypes.data, buf.size, start.ctypes.data)
         _lib.check(rc, "ganet_culane_text")
         return buf, start[:self.B].astype(np.int64), start[self.B + 1:].astype(np.int64)
 
@@ -261,11 +273,14 @@ class BatchLanes(object):
         return [raw[s:s + n].decode("ascii") for s, n in zip(start.tolist(), length.tolist())]
 
 
-def format_batch(packed, B, by_center, downscale, crop_bbox, img_shape, points_thr, threads=0):
+def format_batch(packed, B, by_center, downscale, crop_bbox, img_shape, points_thr, threads=0,
+                 scratch=None):
     """lane_post_process + adjust_result for a whole batch.  `packed`: the int32 record stream
     of ganet_decode_pack on the host (DecodeResult.packed(), HotPath's pinned block, or
     packed_from_images).  Raises ValueError where the reference's int() would
-    (NaN / infinite coordinates)."""
+    (NaN / infinite coordinates).  scratch: a dict kept by the caller between calls (one per
+    thread): the lane buffer in it is reused while large enough (no size query, no
+    allocation); the returned BatchLanes then lives until the next call with that dict."""
     L = _lib.lib()
     packed = np.ascontiguousarray(packed, np.int32)
     f = _lib.LaneFormat()
@@ -276,13 +291,23 @@ def format_batch(packed, B, by_center, downscale, crop_bbox, img_shape, points_t
     f.crop_x0, f.crop_y0, f.crop_x1, f.crop_y1 = (float(v) for v in crop_bbox)
     f.packed_words = packed.size
     need = ctypes.c_size_t(0)
-    rc = L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), None, 0, ctypes.byref(need))
-    if rc not in (_lib.GANET_OK, _lib.GANET_ERR_WORKSPACE):
-        _lib.check(rc, "ganet_lanes_from_packed")
-    out = np.empty(need.value, np.int32)
-    rc = L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), out.ctypes.data, out.size,
-                                   ctypes.byref(need))
+    out = scratch.get("lanes") if scratch is not None else None
+    rc = _lib.GANET_ERR_WORKSPACE
+    if out is not None:
+        rc = L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), out.ctypes.data,
+                                       out.size, ctypes.byref(need))
+    if rc == _lib.GANET_ERR_WORKSPACE:
+        rc = L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), None, 0,
+                                       ctypes.byref(need))
+        if rc not in (_lib.GANET_OK, _lib.GANET_ERR_WORKSPACE):
+            _lib.check(rc, "ganet_lanes_from_packed")
+        out = np.empty(need.value if scratch is None else need.value + need.value // 4 + 64,
+                       np.int32)
+        if scratch is not None:
+            scratch["lanes"] = out
+        rc = L.ganet_lanes_from_packed(packed.ctypes.data, ctypes.byref(f), out.ctypes.data,
+                                       out.size, ctypes.byref(need))
     if rc == _lib.GANET_ERR_NOT_FINITE:
         raise ValueError("cannot convert a non-finite coordinate to integer")
     _lib.check(rc, "ganet_lanes_from_packed")
-    return BatchLanes(out, B, f.threads)
+    return BatchLanes(out[:need.value], B, f.threads)

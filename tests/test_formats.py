@@ -256,3 +256,30 @@ def test_lanes_from_packed_refuses_records_outside_the_buffer():
     far = packed.copy()
     far[8 + 4] = 1 << 30                                               # record offset far outside
     assert call(far, far.size) == _lib.GANET_ERR_BAD_SHAPE
+
+
+def test_format_batch_with_reused_buffers():
+    """scratch=dict: the lane and text buffers are kept between calls (no size query, no
+    allocation while they are large enough); same results as the allocating path, through
+    growing and shrinking batches."""
+    rng = np.random.default_rng(0)
+
+    def img(nk, ng=3):
+        return dict(kpt_gid=rng.integers(-1, ng, nk).astype(np.int32), n_groups=ng,
+                    align=(rng.standard_normal((nk, 2)) * 50 + 100).astype(np.float32),
+                    root=(rng.standard_normal((nk, 2)) * 50 + 100).astype(np.float32),
+                    group_center=rng.integers(0, 100, (ng, 2)).astype(np.int32))
+
+    scratch = {}
+    args = (4, True, 8, (0, 270, 1640, 590), (320, 800, 3), 2)
+    for nk in (30, 80, 10, 200, 5):
+        packed = formats.packed_from_images([img(nk) for _ in range(4)])
+        a = formats.format_batch(packed, *args)
+        b = formats.format_batch(packed, *args, scratch=scratch)
+        assert np.array_equal(a.stream, b.stream)
+        texts = a.culane_texts()
+        buf, start, length = b.culane_text_buffer(scratch=scratch)
+        for i in range(4):
+            assert bytes(buf[start[i]:start[i] + length[i]]).decode("ascii") == texts[i]
+        assert [b.image(i) for i in range(4)] == [a.image(i) for i in range(4)]
+    assert set(scratch) == {"lanes", "text"}
