@@ -22,6 +22,8 @@ from oracle import cpu_oracle as O  # noqa: E402
 
 DEV = torch.device("cuda", 0)
 TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2, torch.float16: 4e-3}
+# half an ulp of the blended value plus half an ulp of the output, against the sum of |terms|
+EPS = {torch.float32: 1e-5, torch.bfloat16: 4e-3, torch.float16: 5e-4}
 
 
 def rnd_conv(rng):
@@ -111,6 +113,15 @@ def fuzz_forward(rng, n):
         got = out.float().cpu().numpy()
         ok = got.shape == ref.shape and np.isfinite(got).all() and \
             float(np.abs(got - ref).max()) <= TOL[dtype] * scale
+        if not ok and got.shape == ref.shape and np.isfinite(got).all():
+            # a handful of outputs can all be small by cancellation; the rounding of the
+            # 16-bit blend is bounded by the sum of the magnitudes of the terms instead
+            mag = O.deform_conv_forward(np.abs(tx.float().cpu().numpy()), off,
+                                        np.abs(tw.float().cpu().numpy()), c["st"], c["pad"], c["dil"],
+                                        c["groups"], c["dg"], mask=mask,
+                                        bias=None if tb is None else np.abs(tb.float().cpu().numpy()),
+                                        nthreads=8)
+            ok = float(np.abs(got - ref).max()) <= EPS[dtype] * float(np.abs(mag).max())
         if not ok:
             err = float(np.abs(got - ref).max()) / scale if got.shape == ref.shape else -1
             print("FAIL (err %.3g) %s" % (err, tag))
