@@ -19,7 +19,7 @@ COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17",
           "-Wall", "-Wno-unused-function"]
 # decode.hip must round like numpy / CPython: no fused multiply-add contraction.
 PER_FILE = {"decode.hip": ["-ffp-contract=off"], "lane_format.hip": ["-ffp-contract=off"]}
-SOURCES = ["api.hip", "decode.hip", "deform_conv.hip", "deform_conv_cts.hip", "deform_conv_stream.hip",
+SOURCES = ["api.hip", "decode.hip", "deform_conv.hip", "deform_conv_cts.hip", "deform_conv_stream.hip", "deform_conv_ring.hip",
            "deform_conv_bwd.hip", "lane_format.hip"]
 
 
@@ -30,6 +30,8 @@ def _newer(a, b):
 def build_lib(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DGANET_ABLATE"] if os.environ.get("GANET_ABLATE") else []  # profiling build
+    if os.environ.get("GANET_RING_DEBUG"):
+        extra.append("-DGANET_RING_DEBUG")
     if os.environ.get("GANET_STREAM_DEBUG"):
         extra.append("-DGANET_STREAM_DEBUG")
         extra += os.environ.get("GANET_STREAM_DEFS", "").split()

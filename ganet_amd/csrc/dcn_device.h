@@ -137,6 +137,14 @@ int stream_forward(const void *xh, const float *offset, const float *mask, const
                    const void *bias, void *out, const ganet_dcn_params *p, int ta, int Cp,
                    int CoutP, void *ws, hipStream_t s);
 
+// the same algorithm with Y kept in the forming XCD's L2 (csrc/deform_conv_ring.hip): teams of
+// workgroups on one XCD form Y tap by tap into a two-plane ring and sample it in the same launch
+bool ring_applicable(const ganet_dcn_params *p, int ta, int Cp, int CoutP, int Ho, int Wo);
+size_t ring_workspace_bytes(const ganet_dcn_params *p);
+int ring_forward(const void *xh, const float *offset, const float *mask, const void *wq,
+                 const void *bias, void *out, const ganet_dcn_params *p, int ta, int Cp,
+                 void *ws, hipStream_t s);
+
 // exact-float32 GEMM of the same file, for the backward (csrc/deform_conv_bwd.hip)
 int cts_gemm_f32(const float *x, const float *wq, float *y, long long M, int K, int N,
                  hipStream_t s);

@@ -604,6 +604,7 @@ struct Plan {
   bool cts;      // contract-then-sample path (deform_conv_cts.hip)
   bool split;    // ... with float32 tensors contracted as three bf16 passes
   bool stream;   // ... as one persistent producer/consumer launch (deform_conv_stream.hip)
+  bool ring;     // ... as one launch with Y kept in L2, tap-major (deform_conv_ring.hip)
   bool keep_y;   // the whole batch's per-tap products stay in the workspace (GANET_DCN_ALGO_KEEP_Y)
   int nb;        // images per chunk of the contract-then-sample pair
   size_t xh_bytes, wp_bytes, y_bytes;
@@ -686,24 +687,28 @@ int make_plan(const ganet_dcn_params *p_in, Plan *pl) {
   // Sampling and contraction commute; contract first when that shrinks the rows
   // that have to be gathered and blended (Cout < Cin, as in the LFA).
   pl->cts = cts_applicable(p, pl->Cp, pl->CoutP) && p->algo != 1;
-  if (p->algo < 0 || p->algo > 3) return GANET_ERR_BAD_SHAPE;
+  if (p->algo < 0 || p->algo > 4) return GANET_ERR_BAD_SHAPE;
   if (p->algo == 2 && !pl->cts) return GANET_ERR_UNSUPPORTED;
   pl->split = pl->cts && pl->ta == GANET_F32 && cts_split(p, pl->Cp);
   pl->stream = pl->cts && p->algo == 3 &&
                stream_applicable(p, pl->ta, pl->Cp, pl->CoutP, pl->Ho, pl->Wo);
   if (p->algo == 3 && !pl->stream) return GANET_ERR_UNSUPPORTED;
+  pl->ring = pl->cts && p->algo == 4 &&
+             ring_applicable(p, pl->ta, pl->Cp, pl->CoutP, pl->Ho, pl->Wo);
+  if (p->algo == 4 && !pl->ring) return GANET_ERR_UNSUPPORTED;
   // keeping Y for the backward: float32 tensors in the default arithmetic (the backward forms
   // the same three-pass products), one chunk for the whole batch
   pl->keep_y = keep_y;
-  if (keep_y && (!pl->split || pl->stream || p->Cout % 64)) return GANET_ERR_UNSUPPORTED;
+  if (keep_y && (!pl->split || pl->stream || pl->ring || p->Cout % 64)) return GANET_ERR_UNSUPPORTED;
   pl->nb = 0;
-  if (pl->cts && !pl->stream) {
+  if (pl->cts && !pl->stream && !pl->ring) {
     pl->nb = keep_y ? p->B : cts_chunk_images(p, pl->CoutP, pl->ta, pl->split);
     const unsigned long long img_y = (unsigned long long)p->H * p->W * pl->T * pl->CoutP *
                                      dtype_size(pl->ta);
     if (img_y * (unsigned long long)pl->nb >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
   }
   pl->y_bytes = pl->stream ? stream_workspace_bytes(p, pl->CoutP)
+                : pl->ring ? ring_workspace_bytes(p)
                            : (pl->cts ? cts_y_bytes(p, pl->CoutP, pl->ta, pl->nb) : 0);
   return GANET_OK;
 }
@@ -787,13 +792,13 @@ extern "C" size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p) {
 extern "C" int ganet_deform_conv_algorithm(const ganet_dcn_params *p) {
   Plan pl;
   if (!p || make_plan(p, &pl) != GANET_OK) return 0;
-  return pl.stream ? 3 : (pl.cts ? 2 : 1);
+  return pl.ring ? 4 : (pl.stream ? 3 : (pl.cts ? 2 : 1));
 }
 
 extern "C" size_t ganet_deform_conv_status_offset(const ganet_dcn_params *p) {
   Plan pl;
-  if (!p || make_plan(p, &pl) != GANET_OK || !pl.stream) return (size_t)-1;
-  return pl.xh_bytes;   // the control block's first word (CTL_ERROR) leads algorithm 3's scratch
+  if (!p || make_plan(p, &pl) != GANET_OK || !(pl.stream || pl.ring)) return (size_t)-1;
+  return pl.xh_bytes;   // the control block's first word (the status) leads algorithm 3's and 4's scratch
 }
 
 extern "C" size_t ganet_deform_conv_y_offset(const ganet_dcn_params *p) {
@@ -882,6 +887,8 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
       pack_weight_dispatch(p, pl, weight, ws + pl.xh_bytes + pl.y_bytes, s) != GANET_OK)
     return GANET_ERR_HIP;
 
+  if (pl.ring)
+    return ring_forward(pl.copy_x ? xh : x, offset, mask, wp, bias, out, p, pl.ta, pl.Cp, ybuf, s);
   if (pl.stream)
     return stream_forward(pl.copy_x ? xh : x, offset, mask, wp, bias, out, p, pl.ta, pl.Cp,
                           pl.CoutP, ybuf, s);

@@ -112,7 +112,13 @@ typedef struct {
                                3 = algorithm 2 as ONE persistent launch (16-bit
                                arithmetic, Cout <= 64 per tap, "same" output
                                size; opt-in, never chosen automatically:
-                               slower than 2 on MI355X so far).
+                               slower than 2 on MI355X so far);
+                               4 = algorithm 2 as ONE launch with the per-tap
+                               products kept in the forming XCD's L2 (formed tap by
+                               tap into a two-plane ring that is overwritten in
+                               place; 16-bit arithmetic, Cin 64/128/256, Cout <= 64,
+                               "same" output size, <= 16 taps, H*W <= 4096; needs
+                               the 8 x 32-CU layout of MI355X).
                                | GANET_DCN_ALGO_KEEP_Y: training - see below */
   int32_t debug;            /* must be 0 (ablation bits of profiling builds) */
 } ganet_dcn_params;
@@ -145,12 +151,12 @@ int ganet_dcn_out_size(int in, int pad, int dilation, int k, int stride);
  * Returns 0 for invalid parameters. */
 size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p);
 
-/* Which algorithm ganet_deform_conv_forward runs for `p`: 1, 2 or 3 as in
+/* Which algorithm ganet_deform_conv_forward runs for `p`: 1, 2, 3 or 4 as in
  * ganet_dcn_params.algo (0 for invalid parameters).  No counterpart in the
  * reference; for logs and benchmarks. */
 int ganet_deform_conv_algorithm(const ganet_dcn_params *p);
 
-/* Algorithm 3 synchronises its workgroups through counters in the workspace; every wait
+/* Algorithms 3 and 4 synchronise their workgroups through counters in the workspace; every wait
  * is bounded, and a wait that runs out (a launch the GPU could not keep resident) leaves
  * a non-zero 32-bit word in the workspace instead of hanging: the output is then invalid.
  * Returns that word's byte offset inside `workspace` for `p`, or (size_t)-1 when the
