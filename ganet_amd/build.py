@@ -10,8 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libganet_hip.so")
-OBJ_DIR = os.path.join(HERE, "csrc", "build")
+_PRODUCT_LIB = os.path.join(HERE, "libganet_hip.so")
+_PRODUCT_OBJ = os.path.join(HERE, "csrc", "build")
+LIB, OBJ_DIR = _PRODUCT_LIB, _PRODUCT_OBJ
 
 ARCH = "gfx950"
 COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17",
@@ -27,26 +28,55 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build_lib(force=False, verbose=False):
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+def _variant_flags():
+    """Extra -D flags of the profiling / debug builds asked for through the environment."""
     extra = ["-DGANET_ABLATE"] if os.environ.get("GANET_ABLATE") else []  # profiling build
     if os.environ.get("GANET_RING_DEBUG"):
         extra.append("-DGANET_RING_DEBUG")
+    extra += os.environ.get("GANET_RING_DEFS", "").split()
     if os.environ.get("GANET_STREAM_DEBUG"):
         extra.append("-DGANET_STREAM_DEBUG")
         extra += os.environ.get("GANET_STREAM_DEFS", "").split()
+    return extra
+
+
+def build_lib(force=False, verbose=False):
+    """The product library; with variant flags in the environment (GANET_ABLATE, GANET_RING_DEBUG,
+    GANET_RING_DEFS, GANET_STREAM_DEBUG) a SEPARATE library libganet_hip_<tag>.so with objects of
+    its own, so that a debug or ablation build can never be picked up as the product library
+    afterwards (load it with GANET_HIP_LIB=<path>)."""
+    global LIB, OBJ_DIR
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = _variant_flags()
+    LIB, OBJ_DIR = _PRODUCT_LIB, _PRODUCT_OBJ
+    if extra:
+        import hashlib
+        tag = hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8]
+        LIB = os.path.join(HERE, "libganet_hip_%s.so" % tag)
+        OBJ_DIR = os.path.join(HERE, "csrc", "build_" + tag)
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(ROOT, "include", "ganet_hip.h"), os.path.join(CSRC, "dcn_device.h"),
                os.path.join(CSRC, "common.h")]
     srcs = [os.path.join(CSRC, src) for src in SOURCES]
-    if not force and not extra and os.path.exists(LIB) and \
+    if not force and os.path.exists(LIB) and \
             not any(_newer(f, LIB) for f in srcs + headers):
         # the library is newer than everything it is built from: on the GPU box the
         # objects do not travel (.gpurunignore) but the library does, and is used as it is
         return LIB
     objs, relink = [], force or not os.path.exists(LIB)
+    # flags named after one source file only rebuild that file; the rest are the product's objects
+    only = {"-DGANET_RING": "deform_conv_ring.hip", "-DGANET_STREAM": "deform_conv_stream.hip"}
+    touched = {v for f in extra for k, v in only.items() if f.startswith(k)}
+    narrow = bool(extra) and all(any(f.startswith(k) for k in only) for f in extra)
+    if narrow:
+        build_lib_product = [os.path.join(_PRODUCT_OBJ, src.replace(".hip", ".o")) for src in SOURCES]
+        if not all(os.path.exists(o) for o in build_lib_product):
+            raise RuntimeError("build the product library first (python -m ganet_amd.build)")
     for src in SOURCES:
         s = os.path.join(CSRC, src)
+        if narrow and src not in touched:
+            objs.append(os.path.join(_PRODUCT_OBJ, src.replace(".hip", ".o")))
+            continue
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in headers):
@@ -64,5 +94,4 @@ def build_lib(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build_lib(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -6,35 +6,43 @@
 // out = sum_t sample(Y_t), and pays for it with Y's round trip through the fabric: 918 of the
 // 1272 MB one LFA call moves at 128 images.  Here Y never leaves the XCD that formed it:
 //
-//   * a TEAM of 32 workgroups (512 threads each, two workgroups per CU, so two teams per
-//     XCD) owns one image at a time; the 256 waves of a team own 16 pixels each and keep
-//     those pixels' x (16 x Cin) in registers as MFMA operands for the image's whole life;
-//   * Y is formed TAP-MAJOR: in step n every wave multiplies its x block with W_t (32 KB,
-//     staged in LDS as ready-made 16x16x32 operand images) and stores its 16 pixels of plane
-//     t (128 B per pixel) into slot n % 2 of the team's ring: two planes of H*W*128 B, the
-//     same 1 MB of addresses for every tap and every image, so the lines are dirtied again
-//     in L2 instead of being written back;
-//   * in the same step the wave gathers plane n-1 from the other slot (8 lanes x 16 B per
-//     pixel, a corner outside the map reads 0 through the buffer bounds check) and adds it
-//     into the fp32 sums of the 16 output pixels it owns; sums, x and coordinates stay in
-//     registers / LDS across the T taps.
+//   * the 32 workgroups of an XCD (1024 threads each, one per CU) are a TEAM that owns two
+//     images at a time (half 0: waves 0..255 of the team, half 1: waves 256..511); a wave
+//     owns 16 pixels of its image and keeps their x (16 x Cin) in registers as MFMA operands
+//     for the image's whole life;
+//   * Y is formed TAP-MAJOR: in step m every wave multiplies its x block with W_t (32 KB,
+//     staged in LDS two steps ahead as ready-made 16x16x32 operand images, double buffered)
+//     and stores its 16 pixels of plane m (128 B per pixel) into slot m % 3 of the team's
+//     ring: three planes of 2 * H*W*128 B, the same 3 MB of addresses for every tap and every
+//     image, so the lines are dirtied again in L2 instead of being written back;
+//   * in the same step the wave gathers plane m-2 (8 lanes x 16 B per pixel, a corner
+//     outside the map reads 0 through the buffer bounds check) and adds it into the fp32 sums
+//     of the 16 output pixels it owns; sums, x and coordinates stay in registers / LDS across
+//     the T taps.
 //
 // Schedule: static.  A workgroup reads its XCD from the hardware register and draws a ticket
-// from that XCD's counter: ticket / 32 is its team, ticket % 32 its rank; team g takes
-// images g, g + 16, ...  There are no queues and no claims.  One barrier per step and team
-// (a monotonic counter in the team's own cache line: one add per workgroup, polled by one
-// lane per workgroup) orders "plane n is complete" before its gathers and "plane n-2 has
-// been read" before slot n % 2 is overwritten; the MFMAs of step n+1 run between a
-// workgroup's arrival and its wait.
+// from that XCD's counter: the ticket is its rank in the team; team x takes images x, 8 + x
+// (first pair), 16 + x, 24 + x, ...  There are no queues and no claims.  Flow control is one
+// monotonic counter per team in a cache line of its own.  A workgroup adds 1 in the middle of
+// every step m, behind its MFMAs (ARRIVAL m), once every wave of it has seen the previous
+// step's store complete - which a counted s_waitcnt tells without draining the gathers just
+// sent, because a wave's vector memory operations complete in order.  Arrival m of every
+// workgroup says that planes <= m-1 have reached L2 and that the gathers of planes <= m-3 have
+// returned, which is what it takes to gather plane m-1 and to overwrite plane m-3's slot with
+// plane m: one condition per step, checked at the END of step m for arrivals posted in its
+// middle.  Nothing is drained inside the loop, and the only workgroup barrier of a step (the
+// weights' double buffer and the arrival need one) stands between the MFMAs and the blend.
 // Visibility: producer and consumer share one L2 by construction (teams are formed per
 // XCC id), Y is stored by plain stores (they stay in L2), every storing wave drains them
 // (s_waitcnt vmcnt(0)) before its workgroup arrives, and every load of Y is an sc1 load
 // (served by L2, never by the CU's L1, which may hold the slot's previous plane).
-// Every wait is bounded; a wait that runs out leaves a non-zero status word and every wave
-// leaves.  The last workgroup to finish checks that every image was taken by some team.
+// Every wait is bounded; a wait that runs out leaves a non-zero status word, and the waves
+// that see it stop touching memory and only keep their workgroup's barriers.  The last
+// workgroup to finish checks that every image was taken by some team.
 //
 // Arithmetic of the sampling position and weights: deform_conv_cuda_kernel.cu:84-115,
-// 218-229 (and :604-627 for the DCNv2 mask), unchanged; blend order as in algorithm 2.
+// 218-229 (and :604-627 for the DCNv2 mask), unchanged; blend order as in algorithm 2, and
+// the products are the same bits (fp32 accumulation over the channels in the same order).
 
 #include "dcn_device.h"
 #include <cstdlib>
@@ -43,19 +51,25 @@ namespace ganet_dcn {
 
 namespace {
 
-constexpr int RW = 8;                        // waves per workgroup
+constexpr int RW = 16;                       // waves per workgroup, one workgroup per CU
 constexpr int RNT = RW * 64;
-constexpr int TEAM_WGS = 32;                 // workgroups per team
-constexpr int TEAMS_PER_XCD = 2;
-constexpr int RING_XCDS = 8;
-constexpr int NTEAMS = RING_XCDS * TEAMS_PER_XCD;
+constexpr int TEAM_WGS = 32;                 // workgroups per team = CUs per XCD
+constexpr int RING_XCDS = 8;                 // teams
+constexpr int HALVES = 2;                    // images a team works on at a time
 constexpr int WPX = 16;                      // pixels per wave
-constexpr int TEAM_PX = TEAM_WGS * RW * WPX; // 4096 pixels per plane
-constexpr int NSLOT = 2;
+constexpr int HALF_WAVES = TEAM_WGS * RW / HALVES;
+constexpr int HALF_PX = HALF_WAVES * WPX;    // 4096 pixels per image
+constexpr int NSLOT = 3;
 constexpr int PXB = 128;                     // bytes per pixel of a plane (64 outputs)
 constexpr int RING_TMAX = 16;                // taps
 constexpr unsigned long long RING_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz clock
-constexpr int AUX_SC1 = 16;
+#ifndef GANET_RING_GATHER_AUX
+#define GANET_RING_GATHER_AUX 16             /* sc1: served by L2, never by the CU's L1 */
+#endif
+constexpr int AUX_SC1 = GANET_RING_GATHER_AUX;
+#ifndef GANET_RING_STORE_MOD
+#define GANET_RING_STORE_MOD ""              /* cache policy of the Y stores (tuning builds: " nt", ...) */
+#endif
 
 // control block (32-bit words); hot words sit in 128-byte lines of their own
 enum {
@@ -64,9 +78,8 @@ enum {
   RCTL_FINISHED = 1 * RL,
   RCTL_IMAGES = 2 * RL,
   RCTL_JOIN = 3 * RL,                        // [8] one line per XCC id
-  RCTL_BAR = RCTL_JOIN + RING_XCDS * RL,     // [NTEAMS] one line per team
-  RCTL_STAMPS = RCTL_BAR + NTEAMS * RL,      // debug builds: 8 x 64-bit phase sums
-  RCTL_WORDS = RCTL_STAMPS + RL
+  RCTL_BAR = RCTL_JOIN + RING_XCDS * RL,     // [8] one line per team
+  RCTL_WORDS = RCTL_BAR + RING_XCDS * RL
 };
 constexpr size_t RING_CTL_BYTES = 4096;
 static_assert(RCTL_WORDS * 4 <= RING_CTL_BYTES, "control block");
@@ -74,7 +87,7 @@ static_assert(RCTL_WORDS * 4 <= RING_CTL_BYTES, "control block");
 struct RingArgs {
   const void *x;        // [B][H*W][KH] channel-last, 16-bit arithmetic dtype
   const void *wq;       // [T][64][KH]
-  unsigned char *ring;  // [NTEAMS][NSLOT][plane_bytes]
+  unsigned char *ring;  // [RING_XCDS][NSLOT][HALVES][plane_bytes]
   const float *offset;  // [B][2T][H][W]
   const float *mask;    // [B][T][H][W] or nullptr
   const void *bias;     // [Cout] or nullptr
@@ -84,9 +97,7 @@ struct RingArgs {
   int kW, pH, pW, dH, dW;
   int out_nhwc, relu, points;
   unsigned plane_bytes;
-  int grid;             // workgroups launched (RING_XCDS * TEAMS_PER_XCD * TEAM_WGS)
-  int debug;            // timing experiments: bit0 nothing produced, bit1 nothing sampled,
-                        // bit2 no waiting at the team barrier (results then undefined)
+  int grid;             // workgroups launched (RING_XCDS * TEAM_WGS)
 };
 
 typedef __attribute__((address_space(1))) unsigned int rgu32;
@@ -107,16 +118,6 @@ __device__ __forceinline__ void rwave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// workgroup barrier that waits for LDS traffic only: vector loads stay in flight across it
-__device__ __forceinline__ void wg_barrier_lds() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-// ... and one that first drains every vector memory operation of the wave (stores of Y,
-// gathers, LDS-DMA of the next weights)
-__device__ __forceinline__ void wg_barrier_drain() {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <typename TA>
@@ -188,26 +189,46 @@ __device__ __forceinline__ uint4 ring_entry(const A &a, int ho, int wo, int t, f
   return make_uint4(e0, __float_as_uint(lh), __float_as_uint(lw), __float_as_uint(m));
 }
 
-#ifdef GANET_RING_DEBUG
-#define RDEBUG(a, bit) ((a).debug & (bit))
-#define RSTAMP_DECL unsigned long long rs_t = __builtin_amdgcn_s_memtime(), rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define RSTAMP(ph)                                                  \
-  do {                                                              \
-    const unsigned long long rs_n = __builtin_amdgcn_s_memtime();   \
-    rs_acc[ph] += rs_n - rs_t;                                      \
-    rs_t = rs_n;                                                    \
-  } while (0)
-#else
-#define RDEBUG(a, bit) 0
-#define RSTAMP_DECL
-#define RSTAMP(ph) do {} while (0)
+// Timing experiments, compiled in by -DGANET_RING_ABLATE=<bits> (a separate library, see
+// ganet_amd/build.py): 1 nothing produced (no MFMA, no x load, no Y store), 2 nothing sampled,
+// 4 no waiting on the team's counter, 8 no weight staging.  Results are then undefined.
+#ifndef GANET_RING_ABLATE
+#define GANET_RING_ABLATE 0
 #endif
+#define RABL(bit) (GANET_RING_ABLATE & (bit))
 
 // the wave's s_waitcnt forms the compiler's own wait bookkeeping understands (gfx9 encoding:
 // vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14)
 #define RING_WAIT_ALL() __builtin_amdgcn_s_waitcnt(0x0070)        /* vmcnt(0) lgkmcnt(0) */
 #define RING_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xc07f)        /* lgkmcnt(0) */
 #define RING_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// Vector memory operations the compiler's wait bookkeeping must not see: beside a pending
+// store or atomic it stops counting (stores and loads are different event kinds to it, so it
+// waits for vmcnt(0) ahead of every use of a loaded register), and beside an LDS-DMA in flight it
+// waits for vmcnt(0) ahead of every LDS read.  The hardware completes them in issue order with the
+// loads, which the waits written out in the step loop rely on; an unseen operation only makes
+// the compiler's own counted waits wait for more.  None of them has a register result.
+__device__ __forceinline__ void asm_store128(const void *sbase, unsigned voff, const u32x4 &v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2" GANET_RING_STORE_MOD ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void asm_store128_64(const void *sbase, unsigned voff, const u32x4 &v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 offset:64" GANET_RING_STORE_MOD ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void asm_atomic_inc(const void *sbase) {
+  const unsigned zero = 0u, one = 1u;
+  asm volatile("global_atomic_add %0, %1, %2" ::"v"(zero), "v"(one), "s"(sbase) : "memory");
+}
+// LDS-DMA of 16 bytes per lane: LDS destination = lds_dst (wave-uniform byte address) + 16 * lane
+__device__ __forceinline__ void asm_glds128(const void *sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
 
 __device__ __forceinline__ int rsgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // a wave-uniform value the optimiser may not look through: what is computed from it stays where
@@ -237,15 +258,15 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
   constexpr int TROW = RING_TMAX + 1;        // entries per pixel row (+1: rows start on different banks)
   constexpr int TAB_BYTES = RW * WPX * TROW * 16;
   typedef typename Mma16<TA>::frag frag_t;
-  // one array: weights, the waves' coordinate tables, a few words of workgroup state
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[W_BYTES + TAB_BYTES + 64];
-  int *s_info = reinterpret_cast<int *>(smem + W_BYTES + TAB_BYTES);
+  // one array: two weight buffers, the waves' coordinate tables, a few words of workgroup state
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * W_BYTES + TAB_BYTES + 64];
+  int *s_info = reinterpret_cast<int *>(smem + 2 * W_BYTES + TAB_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = rsgpr(tid >> 6);
   unsigned int *ctl = a.ctl;
 
-  // ---- join: XCD, team, rank ------------------------------------------------------------
+  // ---- join: XCD = team, rank ------------------------------------------------------------
   if (tid == 0) {
     unsigned xid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
@@ -253,42 +274,42 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
     const unsigned ticket = rflag_add(&ctl[RCTL_JOIN + xid * RL], 1u);
     s_info[0] = (int)xid;
     s_info[1] = (int)ticket;
-    s_info[2] = 0;                           // failure word of the workgroup
   }
   __syncthreads();
   const int xcc = rsgpr(s_info[0]);
-  const int ticket = rsgpr(s_info[1]);
-  const int team_x = ticket / TEAM_WGS, rank = ticket - team_x * TEAM_WGS;
-  const int team = xcc * TEAMS_PER_XCD + team_x;
-  const bool seated = team_x < TEAMS_PER_XCD;  // else: more workgroups on this XCD than the schedule has
+  const int rank = rsgpr(s_info[1]);
+  const bool seated = rank < TEAM_WGS;       // else: more workgroups on this XCD than the schedule has
   const int HW = a.H * a.W;
   const int T = a.T;
-  const int nimg = (!seated || team >= a.B) ? 0 : (a.B - team + NTEAMS - 1) / NTEAMS;
-  const int NP = rsgpr(nimg * T);
-  bool failed = false;
+  // images of this team: xcc, xcc + 8, ...; two at a time
+  const int nimg = (!seated || xcc >= a.B) ? 0 : (a.B - xcc + RING_XCDS - 1) / RING_XCDS;
+  const int npairs = (nimg + HALVES - 1) / HALVES;
+  const int NP = rsgpr(npairs * T);
   if (!seated && tid == 0) rflag_store(&ctl[RCTL_ERROR], 2u);
 
   if (NP > 0) {
-    unsigned int *bar = rsgpr_ptr(ctl + RCTL_BAR + team * RL);
+    unsigned int *bar = rsgpr_ptr(ctl + RCTL_BAR + xcc * RL);
     // pixels: the wave's 16 as MFMA columns (lane & 15) and as two gather groups of 8
-    const int px0 = rsgpr((rank * RW + wid) * WPX);
-    const bool active = px0 < HW;            // wave-uniform
+    const int wg = rank * RW + wid;          // wave of the team
+    const int half = rsgpr(wg / HALF_WAVES);
+    const int px0 = rsgpr((wg - half * HALF_WAVES) * WPX);
+    const bool has_px = px0 < HW;            // wave-uniform
     const int mc = lane & 15, mg = lane >> 4;  // MFMA: column (pixel), k group / row group
     const int pxg = lane >> 3, pj = lane & 7;  // gather: pixel of the group, 16-byte piece
-    unsigned char *ring = rsgpr_ptr(a.ring + (size_t)team * NSLOT * a.plane_bytes);
-    const __amdgpu_buffer_rsrc_t ysrc =
-        __builtin_amdgcn_make_buffer_rsrc(ring, 0, (int)(NSLOT * a.plane_bytes), 0x00020000);
-    const int row_bytes = a.W * PXB;
     const unsigned plane_bytes = a.plane_bytes;
-    const uint4 *tab_rd = reinterpret_cast<const uint4 *>(smem + W_BYTES) + wid * (WPX * TROW) + pxg * TROW;
-    uint4 *tab_wr = reinterpret_cast<uint4 *>(smem + W_BYTES) + wid * (WPX * TROW) + pxg * TROW;
+    const unsigned slot_bytes = HALVES * plane_bytes;
+    unsigned char *ring = rsgpr_ptr(a.ring + (size_t)xcc * NSLOT * slot_bytes + (size_t)half * plane_bytes);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+        ring, 0, (int)(NSLOT * slot_bytes - half * plane_bytes), 0x00020000);
+    const int row_bytes = a.W * PXB;
+    const uint4 *tab_rd = reinterpret_cast<const uint4 *>(smem + 2 * W_BYTES) + wid * (WPX * TROW) + pxg * TROW;
+    uint4 *tab_wr = reinterpret_cast<uint4 *>(smem + 2 * W_BYTES) + wid * (WPX * TROW) + pxg * TROW;
     const unsigned char *xbytes = static_cast<const unsigned char *>(a.x);
     const unsigned char *wq = static_cast<const unsigned char *>(a.wq);
     const size_t img_x_bytes = (size_t)HW * KH * 2;
+    const int B = a.B;
 
     // per-lane byte offsets (32 bit) against wave-uniform bases
-    const int pm = px0 + mc < HW ? px0 + mc : HW - 1;
-    const unsigned x_off = (unsigned)pm * (KH * 2) + (unsigned)mg * 16u;
     const unsigned y_off = (unsigned)(px0 + mc) * PXB + (unsigned)mg * 16u;
     const bool y_ok = px0 + mc < HW;
     // weights of tap t into LDS as operand images: image (m, ks) holds, for lane l, the 16
@@ -296,16 +317,15 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
     // 32 (m >> 1) + 8 g + 4 (m & 1) + i: accumulator register i of lane (pixel, g) in tiles
     // 2h, 2h + 1 then holds outputs 32 h + 8 g .. +8 of that pixel, 16 contiguous bytes of Y.
     const unsigned w_off = (unsigned)((8 * ((lane & 15) >> 2) + (lane & 3)) * KH + (lane >> 4) * 8) * 2u;
-    auto stage_weights = [&](int t) {
+    const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;   // LDS byte address of the array
+    auto stage_weights = [&](int t, int buf) {
       t = ropaque(t);
 #pragma unroll
       for (int j = 0; j < NIMG / RW; ++j) {
         const int ii = j * RW + wid;
         const int m = ii / NKS, ks = ii - m * NKS;
-        const unsigned char *base =
-            ropaque_ptr(wq + ((size_t)(t * 64 + 32 * (m >> 1) + 4 * (m & 1)) * KH + ks * 32) * 2);
-        __builtin_amdgcn_global_load_lds((const glb_void *)(base + w_off), (lds_void *)(smem + ii * 1024),
-                                         16, 0, 0);
+        const unsigned char *base = wq + ((size_t)(t * 64 + 32 * (m >> 1) + 4 * (m & 1)) * KH + ks * 32) * 2;
+        asm_glds128(base, w_off, lds_base + (unsigned)(buf * W_BYTES + ii * 1024));
       }
     };
 
@@ -313,13 +333,16 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
     auto load_x = [&](int img) {
       img = ropaque(img);
       const unsigned char *base = ropaque_ptr(xbytes + (size_t)img * img_x_bytes);
+      const int pxo = ropaque(px0), hw = ropaque(HW);   // (formed here, once per image, not kept)
+      const int pm = pxo + mc < hw ? pxo + mc : hw - 1;
+      const unsigned x_off = (unsigned)pm * (KH * 2) + (unsigned)mg * 16u;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) xb[ks] = ldg128(base + x_off + ks * 64);
     };
 
-    // table of image img: lane (pxg, pj) forms taps pj, pj + 8 of pixels pxg and 8 + pxg
-    // the image-edge paths read their arguments again from the kernel argument segment (scalar
-    // loads, once per image) instead of holding them in SGPRs through the step loop
+    // table of image img: lane (pxg, pj) forms taps pj, pj + 8 of pixels pxg and 8 + pxg.
+    // The image-edge paths read their arguments again from the kernel argument segment (scalar
+    // loads, once per image) instead of holding them in SGPRs through the step loop.
     typedef const __attribute__((address_space(4))) RingArgs *cargs_t;
     auto form_table = [&](int img) {
       img = ropaque(img);
@@ -407,166 +430,201 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
       }
     };
 
-    RSTAMP_DECL;
-    // ---- prologue: the first image's weights, x and coordinates -----------------------
-    stage_weights(0);
-    if (active) {
-      load_x(team);
-      form_table(team);
+    // image of pair i for this wave's half, and whether the wave has work on it
+    auto image_of = [&](int pair) { return (pair * HALVES + half) * RING_XCDS + xcc; };
+
+    // ---- the team's counter: `seen` is the last value this wave has read (monotonic) -------
+    unsigned seen = 0;
+    bool dead = false;                       // a wait ran out somewhere: only barriers from now on
+    auto wait_count = [&](unsigned target) {
+      if (seen >= target || dead || RABL(4)) return;
+      int st = 0;
+      if (lane == 0) {
+        unsigned s = rflag_load(bar);
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        while (s < target) {
+          __builtin_amdgcn_s_sleep(1);
+          s = rflag_load(bar);
+          if ((++spins & 255) == 0) {
+            if (t0 == 0) t0 = __builtin_amdgcn_s_memrealtime();
+            if (rflag_load(&ctl[RCTL_ERROR]) != 0) {
+              st = 1;
+              break;
+            }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > RING_TIMEOUT_TICKS) {
+              rflag_store(&ctl[RCTL_ERROR], 1u);
+              st = 1;
+              break;
+            }
+          }
+        }
+        seen = s;
+      }
+      seen = (unsigned)rsgpr((int)seen);
+      if (rsgpr(st)) dead = true;
+    };
+
+    // ---- prologue: the first two taps' weights, the first image's x and coordinates -------
+    if (!RABL(8)) {
+      stage_weights(0, 0);
+      if (NP > 1) stage_weights(1 % T, 1);
+    }
+    if (has_px && image_of(0) < B) {
+      if (!RABL(1)) load_x(image_of(0));
+      form_table(image_of(0));
     }
     zero_out();
     RING_WAIT_ALL();
     RING_BARRIER();
-    RSTAMP(0);
-
-    int t = 0, img = team;                   // tap and image of plane n
-    for (int n = 0; n <= NP; ++n) {
-      const bool do_mfma = n < NP;
-      const bool do_gather = n >= 1;
-      const int tp = t == 0 ? T - 1 : t - 1; // tap of plane n - 1
-      const bool img_edge = do_gather && t == 0;   // plane n - 1 closed its image
-
-      // the poll of barrier n-1 goes out ahead of the MFMAs
-      unsigned seen = 0;
-      if (do_gather && wid == 0 && lane == 0) seen = rflag_load(bar);
-
-      // ---- plane n = x_block * W_t^T on the matrix cores --------------------------------
-      u32x4 ypk[2];
-      if (do_mfma && active && !RDEBUG(a, 1)) {
-        f32x4 acc[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const u32x4 *wimg = reinterpret_cast<const u32x4 *>(smem) + lane;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          const frag_t fb = __builtin_bit_cast(frag_t, xb[ks]);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const frag_t fa = __builtin_bit_cast(frag_t, wimg[(m * NKS + ks) * 64]);
-            acc[m] = Mma16<TA>::mma(fa, fb, acc[m]);
-          }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          TA v[8];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = from_f32<TA>(acc[2 * h][i]);
-            v[4 + i] = from_f32<TA>(acc[2 * h + 1][i]);
-          }
-          __builtin_memcpy(&ypk[h], v, 16);
-        }
-        // the image's last tap is done: the next image's x takes the registers
-        if (t == T - 1 && n + 1 < NP) load_x(img + NTEAMS);
-      }
-      RSTAMP(1);
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(xb[ks]));   // (x is complete: see step 5)
 
-      // ---- team barrier n-1: plane n-1 is complete, slot n % 2 has been read ------------
-      if (do_gather && wid == 0) {
-        int fail = 0;
-        if (lane == 0 && !RDEBUG(a, 4)) {
-          const unsigned target = (unsigned)TEAM_WGS * (unsigned)n;
-          unsigned spins = 0;
-          unsigned long long t0 = 0;
-          while (seen < target) {
-            __builtin_amdgcn_s_sleep(1);
-            seen = rflag_load(bar);
-            if ((++spins & 255) == 0) {
-              if (t0 == 0) t0 = __builtin_amdgcn_s_memrealtime();
-              if (rflag_load(&ctl[RCTL_ERROR]) != 0) {
-                fail = 1;
-                break;
-              }
-              if (__builtin_amdgcn_s_memrealtime() - t0 > RING_TIMEOUT_TICKS) {
-                rflag_store(&ctl[RCTL_ERROR], 1u);
-                fail = 1;
-                break;
-              }
-            }
-          }
-        }
-        fail = rsgpr(fail);
-        if (fail && lane == 0) s_info[2] = 1;
-      }
-      RING_WAIT_LDS();
-      RING_BARRIER();
-      if (rsgpr(s_info[2])) {
-        failed = true;
-        break;
-      }
-      RSTAMP(2);
+    // Step m of a wave (planes m and m-2; no memory operation is ever drained in the loop, the
+    // in-order completion of a wave's vector memory operations carries the hand-offs):
+    //   1  the gathers of plane m-2 go out (8 loads of 1 KB per wave)
+    //   2  plane m is formed on the matrix cores while they are in flight
+    //   3  vmcnt(8): everything this wave sent before those gathers is complete - the store of
+    //      plane m-1, the weights it staged in step m-1 - then the workgroup's barrier; one lane
+    //      adds the workgroup to the team's counter (ARRIVAL m: planes <= m-1 are stored, the
+    //      gathers of planes <= m-3 have returned)
+    //   4  plane m-2 is blended into the sums; plane m+2's weights go to the buffer plane m's
+    //      sat in; the next image's x is fetched where plane m was an image's last; at an
+    //      image's last tap the sums leave and the next image's coordinates are formed
+    //   5  once the counter shows arrival m of every workgroup - posted half a step ago - plane
+    //      m is stored into slot m % 3 (it held plane m-3) and step m+1 may gather plane m-1
+    u32x4 ypk[2];
+    int t = 0, pair = 0;                     // tap and pair of plane m
+    int tq = 0, pq = 0;                      // ... of plane m-1 (read from m = 1 on)
+    int tg = 0, pg = 0;                      // ... of plane m-2 (read from m = 2 on)
+    for (int m = 0; m <= NP + 1; ++m) {
+      const bool has_m = m < NP;             // plane m exists
+      const bool has_g = m >= 2;             // plane m-2 exists (m - 2 < NP always holds here)
+      const bool act_m = has_m && has_px && image_of(pair) < B && !dead && !RABL(1);
+      const bool act_g = has_g && has_px && image_of(pg) < B && !dead;
 
-      // every wave of the workgroup is past its MFMAs: the next tap's weights may land
-      if (n + 1 < NP) stage_weights(t + 1 == T ? 0 : t + 1);
-
-      // ---- plane n leaves for slot n % 2 -------------------------------------------------
-      if (do_mfma && active && !RDEBUG(a, 1) && y_ok) {
-        unsigned char *dst = ropaque_ptr(ring + (size_t)((n & 1) * plane_bytes));
-        *(GANET_GLOBAL u32x4 *)(dst + y_off) = ypk[0];
-        *(GANET_GLOBAL u32x4 *)(dst + y_off + 64) = ypk[1];
-      }
-
-      // ---- plane n-1 is gathered from the other slot and blended -------------------------
-      if (do_gather && active && !RDEBUG(a, 2)) {
-        const int so = (int)(((n - 1) & 1) * plane_bytes) + pj * 16;
-        u32x4 v[2][4];
-        float lh[2], lw[2], mk[2];
+      // ---- 1: gathers of plane m-2 (the counter was checked at the end of step m-1) --------
+      // Every wave sends its 8 loads in every step - a wave without work sends them out of
+      // bounds, where they cost nothing and read 0 - so that the step is one straight line of
+      // vector memory operations and every wait in it is a counted one.
+      u32x4 v[2][4];
+      if (!RABL(2)) {
+        const int so = (int)((unsigned)((m + NSLOT - 2) % NSLOT) * slot_bytes) + pj * 16;
+        const unsigned off_all = act_g ? 0u : OOB_OFFSET;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          const uint4 e = tab_rd[st * 8 * TROW + tp];
+          const uint4 e = tab_rd[st * 8 * TROW + tg];
           const int base = (int)(e.x & ~15u) + so;
-          const unsigned c1 = (e.x & 1u) ? (unsigned)base : OOB_OFFSET;
-          const unsigned c2 = (e.x & 2u) ? (unsigned)(base + PXB) : OOB_OFFSET;
-          const unsigned c3 = (e.x & 4u) ? (unsigned)(base + row_bytes) : OOB_OFFSET;
-          const unsigned c4 = (e.x & 8u) ? (unsigned)(base + row_bytes + PXB) : OOB_OFFSET;
+          const unsigned c1 = ((e.x & 1u) ? (unsigned)base : OOB_OFFSET) | off_all;
+          const unsigned c2 = ((e.x & 2u) ? (unsigned)(base + PXB) : OOB_OFFSET) | off_all;
+          const unsigned c3 = ((e.x & 4u) ? (unsigned)(base + row_bytes) : OOB_OFFSET) | off_all;
+          const unsigned c4 = ((e.x & 8u) ? (unsigned)(base + row_bytes + PXB) : OOB_OFFSET) | off_all;
           v[st][0] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, c1, 0, AUX_SC1);
           v[st][1] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, c2, 0, AUX_SC1);
           v[st][2] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, c3, 0, AUX_SC1);
           v[st][3] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, c4, 0, AUX_SC1);
-          lh[st] = __uint_as_float(e.y);
-          lw[st] = __uint_as_float(e.z);
-          mk[st] = __uint_as_float(e.w);
         }
+      }
+
+      // ---- 2: plane m = x_block * W_t^T on the matrix cores (weights in buffer m & 1) ------
+      if (act_m) {
+        // One 16x16 tile of outputs at a time (a chain of NKS MFMAs on one accumulator runs at
+        // the pipe's rate), the weight fragments read PF MFMAs ahead.  The order is pinned: left
+        // to itself the scheduler, short of registers here, reads each fragment right before
+        // its MFMA and every MFMA then waits out an LDS round trip.
+        const u32x4 *wimg = reinterpret_cast<const u32x4 *>(smem + (m & 1) * W_BYTES) + lane;
+        constexpr int NF = 4 * NKS, PF = 3;
+        frag_t fr[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) fr[i] = __builtin_bit_cast(frag_t, wimg[i * 64]);
+        TA o[8];
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const int q = i / NKS, ks = i % NKS;
+          const frag_t fa = fr[i % PF];
+          __builtin_amdgcn_sched_barrier(0);
+          acc = Mma16<TA>::mma(fa, __builtin_bit_cast(frag_t, xb[ks]), acc);
+          if (i + PF < NF) fr[i % PF] = __builtin_bit_cast(frag_t, wimg[(i + PF) * 64]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks == NKS - 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[4 * (q & 1) + e] = from_f32<TA>(acc[e]);
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q & 1) __builtin_memcpy(&ypk[q >> 1], o, 16);
+          }
+        }
+      }
+
+      // ---- 3: step m-1 of this wave is complete; barrier; arrival m; weights; x -----------
+      if (!RABL(2))
+        __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): all but the 8 gathers
+      else
+        RING_WAIT_ALL();
+      RING_BARRIER();
+      if (tid == 0 && m >= 1) asm_atomic_inc(bar);
+
+      // ---- 4: blend plane m-2; an image's last tap closes it ------------------------------
+      if (!RABL(2)) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          const float hh = 1.f - lh[st], hw_ = 1.f - lw[st];
-          racc_piece<TA>(v[st][0], hh * hw_ * mk[st], oacc[st]);
-          racc_piece<TA>(v[st][1], hh * lw[st] * mk[st], oacc[st]);
-          racc_piece<TA>(v[st][2], lh[st] * hw_ * mk[st], oacc[st]);
-          racc_piece<TA>(v[st][3], lh[st] * lw[st] * mk[st], oacc[st]);
+          // (the loaded rows are first looked at here: without this the scheduler moves their
+          // unpacking up between the MFMAs, and the barrier then waits for the gathers)
+          asm volatile("" : "+v"(v[st][0]), "+v"(v[st][1]), "+v"(v[st][2]), "+v"(v[st][3]));
+          // (the entry is read again rather than kept in registers across the MFMAs)
+          const uint4 e = tab_rd[st * 8 * TROW + tg];
+          const float lh = act_g ? __uint_as_float(e.y) : 0.f;
+          const float lw = act_g ? __uint_as_float(e.z) : 0.f;
+          const float mk = act_g ? __uint_as_float(e.w) : 0.f;
+          const float hh = 1.f - lh, hw_ = 1.f - lw;
+          racc_piece<TA>(v[st][0], hh * hw_ * mk, oacc[st]);
+          racc_piece<TA>(v[st][1], hh * lw * mk, oacc[st]);
+          racc_piece<TA>(v[st][2], lh * hw_ * mk, oacc[st]);
+          racc_piece<TA>(v[st][3], lh * lw * mk, oacc[st]);
         }
       }
-      RSTAMP(3);
-
-      // ---- an image is complete: its sums leave, the next image's coordinates are formed
-      if (img_edge && active) {
-        store_out(img - NTEAMS);
-        zero_out();
-        if (do_mfma) form_table(img);
+      // (behind the blend: beside an LDS-DMA in flight the compiler waits for every load at once)
+      if (has_m && m + 2 < NP && !RABL(8)) stage_weights((t + 2) % T, m & 1);
+      if (has_g && tg == T - 1) {
+        if (act_g) {
+          store_out(image_of(pg));
+          zero_out();
+          RING_WAIT_ALL();   // (its stores are the only ones the compiler sees: none pending at the join)
+        }
+        if (has_px && !dead && pg + 1 < npairs && image_of(pg + 1) < B) form_table(image_of(pg + 1));
       }
-      RSTAMP(4);
 
-      RING_WAIT_ALL();
-      RING_BARRIER();
-      if (tid == 0) rflag_add(bar, 1u);
-      RSTAMP(5);
+      // ---- 5: arrival m of every workgroup; plane m leaves for slot m % 3 ------------------
+      if (m >= 1 && m <= NP) wait_count((unsigned)TEAM_WGS * (unsigned)m);
+      if (act_m && !dead && y_ok) {
+        const unsigned char *dst = ring + (size_t)(m % NSLOT) * slot_bytes;
+        asm_store128(dst, y_off, ypk[0]);
+        asm_store128_64(dst, y_off, ypk[1]);
+      }
+      // plane m was an image's last: the next image's x takes the registers.  Fetch and wait in
+      // ONE block: the compiler's wait bookkeeping merges paths, and a fetch in one conditional
+      // block with its first use in another makes it wait for every load ahead of every step's
+      // MFMAs, the gathers just sent included.
+      if (act_m && t == T - 1 && image_of(pair + 1) < B) {
+        load_x(image_of(pair + 1));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(xb[ks]));
+      }
+
+      // advance the three (tap, pair) clocks
+      tg = tq; pg = pq;
+      tq = t; pq = pair;
       if (++t == T) {
         t = 0;
-        img += NTEAMS;
+        ++pair;
       }
     }
-#ifdef GANET_RING_DEBUG
-    if (lane == 0)
-      for (int ph = 0; ph < 8; ++ph)
-        __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long *)(ctl + RCTL_STAMPS) + ph,
-                               rs_acc[ph], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
   }
 
   // ---- the launch is complete when every workgroup has finished and every image was taken
   __syncthreads();
   if (tid == 0) {
-    if (!failed && rank == 0 && nimg > 0) rflag_add(&ctl[RCTL_IMAGES], (unsigned)nimg);
+    if (seated && rank == 0 && nimg > 0) rflag_add(&ctl[RCTL_IMAGES], (unsigned)nimg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned f = rflag_add(&ctl[RCTL_FINISHED], 1u);
     if (f + 1u == (unsigned)a.grid) {
@@ -576,11 +634,6 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
   }
 }
 
-int ring_env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return e && *e ? atoi(e) : dflt;
-}
-
 size_t ring_plane_bytes(const ganet_dcn_params *p) {
   return ganet_align_up((size_t)p->H * p->W * PXB, 256);
 }
@@ -588,18 +641,18 @@ size_t ring_plane_bytes(const ganet_dcn_params *p) {
 }  // namespace
 
 // 16-bit arithmetic, Cin in {64, 128, 256} as one K chunk, 64 output channels per tap, "same"
-// output size, at most 16 taps, a whole plane per team (H*W <= 4096 pixels)
+// output size, at most 16 taps, a whole plane per image half of a team (H*W <= 4096 pixels)
 bool ring_applicable(const ganet_dcn_params *p, int ta, int Cp, int CoutP, int Ho, int Wo) {
   if (ta == GANET_F32) return false;
   if (Cp != 64 && Cp != 128 && Cp != 256) return false;
   if (CoutP != 64 || p->deformable_groups != 1 || p->groups != 1) return false;
   if (p->sH != 1 || p->sW != 1 || Ho != p->H || Wo != p->W) return false;
   if (p->kH * p->kW > RING_TMAX) return false;
-  return (long long)p->H * p->W <= TEAM_PX;
+  return (long long)p->H * p->W <= HALF_PX;
 }
 
 size_t ring_workspace_bytes(const ganet_dcn_params *p) {
-  return RING_CTL_BYTES + (size_t)NTEAMS * NSLOT * ring_plane_bytes(p);
+  return RING_CTL_BYTES + (size_t)RING_XCDS * NSLOT * HALVES * ring_plane_bytes(p);
 }
 
 template <typename TA, typename TO>
@@ -641,8 +694,7 @@ int ring_forward(const void *xh, const float *offset, const float *mask, const v
   a.relu = p->fuse_relu;
   a.points = p->offset_is_points;
   a.plane_bytes = (unsigned)ring_plane_bytes(p);
-  a.grid = NTEAMS * TEAM_WGS;
-  a.debug = ring_env_int("GANET_RING_DEBUG_BITS", 0);
+  a.grid = RING_XCDS * TEAM_WGS;
   // the schedule is written for 8 XCDs of 32 CUs
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
