@@ -37,6 +37,10 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3}
 
 WORKLOADS = {
     # name: shape key in ganet_amd.synth.SHAPES, per-GPU batch, Cin, default dtype, decode?
+    "c1": dict(shape="s8_tusimple", B=1, Cin=256, dtype="fp32", decode=True,
+               desc="C1 GANet-S TuSimple 320x800, batch 1: LFA (Cin256->64, K7, 40x100) + "
+                    "keypoint decode/grouping, one image per step (latency case; the "
+                    "reference's own speed test, tools/ganet/speed_test.py:57-65, is batch 1)"),
     "c3": dict(shape="s8_culane", B=128, Cin=256, dtype="bf16", decode=True,
                desc="C3 full head hot path: LFA (Cin256->64, K7) + NMS/decode/grouping, "
                     "CULane 320x800 (40x100 @ s8), batch 128 per GPU"),
@@ -118,6 +122,17 @@ def cpu_baseline_and_parity(wl, dtype, d, hp, n_images, threads):
     parity["lfa_rel_err"] = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
     parity["lfa_tolerance"] = 1e-4 if dtype == "fp32" else 1e-2
     parity["lfa_ok"] = bool(parity["lfa_rel_err"] <= parity["lfa_tolerance"])
+    # the stricter, element-wise yardstick: every output's error against the sum of the
+    # magnitudes of ITS OWN terms, sum_t sum_c |w| * blend(|x|) (the blend weights are >= 0, so
+    # the same oracle on |x|, |w| gives it), on a part of the sample
+    ns = min(n, 32)
+    mag = O.deform_conv_forward(np.abs(x_host[:ns]), off_host[:ns], np.abs(w_host), (1, 1),
+                                (0, (K - 1) // 2), (1, 1), acc64=False, nthreads=threads)
+    parity["lfa_rel_err_vs_terms"] = float(
+        (np.abs(got[:ns] - ref[:ns]) / np.maximum(mag, 1e-30)).max())
+    parity["lfa_rel_err_vs_terms_images"] = ns
+    parity["lfa_ok"] = bool(parity["lfa_ok"] and
+                            parity["lfa_rel_err_vs_terms"] <= parity["lfa_tolerance"])
     if wl["decode"]:
         T = float(cfg["T"])
         t0 = time.perf_counter()
@@ -269,7 +284,12 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="profiling only")
     ap.add_argument("--algo", type=int, default=0,
-                    help="LFA algorithm: 0 auto, 1 sample-then-contract, 2 contract-then-sample")
+                    help="LFA algorithm: 0 auto, 1 sample-then-contract, 2 contract-then-sample, "
+                         "3 / 4 that pair as one persistent launch (opt-in experiments)")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: do not gather the formatted lane lists on rank 0 (A/B)")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1: gather every k-th step's formatted lane lists on rank 0")
     ap.add_argument("--fp32-mode", default="auto", choices=["auto", "bf16", "exact"],
                     help="fp32 tensors: auto = float32-class accuracy (three bf16 MFMA passes "
                          "over hi/lo splits where the contract-then-sample path applies), "
@@ -443,7 +463,35 @@ def main():
     import threading
     fmt_local = threading.local()     # every formatting thread keeps its own output buffers
 
-    def consume(slot):
+    # N > 1: every (k-th) step's formatted lane lists are gathered on rank 0 in image order, as
+    # north_star's path ends ("per-image lane lists gathered on the host"; the reference:
+    # tools/ganet/tusimple/test_dataset.py:252-264, mmdet/apis/test.py:122-166).  A host thread
+    # of its own owns a gloo group for it, so neither the enqueueing thread nor the GPUs'
+    # streams wait for the gather; the timed region ends when the last gather has.
+    gather_q, gather_thread, gather_group = None, None, None
+    gathered = {"steps": 0, "images": 0, "bytes": 0, "lanes": 0, "error": None}
+    if dist is not None and world > 1 and wl["decode"] and not args.no_gather and not args.graph:
+        import queue
+        gather_group = dist.new_group(backend="gloo") if backend != "gloo" else None
+        gather_q = queue.Queue()
+
+    def gather_loop():
+        from ganet_amd import sharding
+        try:
+            while True:
+                item = gather_q.get()
+                if item is None:
+                    return
+                res = sharding.gather_text_blocks(item[0], item[1], dst=0, group=gather_group)
+                if res is not None:
+                    gathered["steps"] += 1
+                    gathered["images"] += len(res[1])
+                    gathered["bytes"] += len(res[0])
+                    gathered["lanes"] += res[0].count(b"\n")   # one line of text per lane
+        except Exception as exc:  # noqa: BLE001
+            gathered["error"] = repr(exc)
+
+    def consume(slot, want_text=False):
         from ganet_amd import formats
         scratch = getattr(fmt_local, "scratch", None)
         if scratch is None:
@@ -451,7 +499,12 @@ def main():
         bl = formats.format_batch(hp.records(slot), B, True, cfg["ds"], fmt_crop, fmt_shape,
                                   fmt_thr, threads=fmt_threads, scratch=scratch)
         buf, start, length = bl.culane_text_buffer(scratch=scratch)
-        return int(bl.n_lanes().sum()), int(length.sum())
+        if gather_q is not None and want_text:
+            # (image b's text is buf[start[b] : start[b] + length[b]]; packed back to back here)
+            mv = memoryview(buf)
+            text = b"".join([mv[a:a + n] for a, n in zip(start.tolist(), length.tolist())])
+            return int(bl.n_lanes().sum()), len(text), (text, length.tolist())
+        return int(bl.n_lanes().sum()), int(length.sum()), None
 
     if graph is not None or not wl["decode"]:
         args.consume = False     # nothing to format / no per-step result block under a graph
@@ -467,6 +520,19 @@ def main():
         pool = ThreadPoolExecutor(max_workers=args.consume_threads)
         for fut in [pool.submit(consume, hp.last) for _ in range(2 * args.consume_threads)]:
             fut.result()
+    if gather_q is not None and not args.consume:
+        gather_q = None          # nothing is formatted inside the timed region: nothing to gather
+    if gather_q is not None:
+        import threading as _th
+        gather_thread = _th.Thread(target=gather_loop, daemon=True)
+        gather_thread.start()
+
+    def take(fut):
+        nl, nb, text = fut.result()
+        consumed[0] += nl
+        consumed[1] += nb
+        if text is not None:
+            gather_q.put(text)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -477,22 +543,25 @@ def main():
     pending = {}
     for i in range(args.steps):
         if pool is not None and hp.cur in pending:
-            nl, nb = pending.pop(hp.cur).result()
-            consumed[0] += nl
-            consumed[1] += nb
+            take(pending.pop(hp.cur))
         if graph is not None:
             graph.replay()
         else:
             one_step(events[i])
         if pool is not None:
-            pending[(hp.cur - 1) % len(hp.slots)] = pool.submit(consume, hp.last)
+            pending[(hp.cur - 1) % len(hp.slots)] = pool.submit(
+                consume, hp.last, gather_q is not None and i % max(1, args.gather_every) == 0)
     for fut in pending.values():
-        nl, nb = fut.result()
-        consumed[0] += nl
-        consumed[1] += nb
+        take(fut)
     if pool is not None:
         pool.shutdown()
+    if gather_thread is not None:
+        gather_q.put(None)
+        gather_thread.join()
+        if gathered["error"]:
+            raise SystemExit("gather of the lane lists failed: " + gathered["error"])
     torch.cuda.synchronize()          # all streams of the device, copies included
+    hp.check_lfa()                    # algorithms 3 / 4: no wait inside a launch ran out
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -561,6 +630,8 @@ def main():
             roof = dict(bound="hbm", achieved=hbm_achieved, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=hbm_achieved / HBM_PEAK_GBS)
         kernels = ("dcn_fused_kernel" if hp.lfa_algorithm == 1 else
+                   "lfa_stream_kernel" if hp.lfa_algorithm == 3 else
+                   "lfa_ring_kernel" if hp.lfa_algorithm == 4 else
                    "%s + cts_sample_kernel (all chunk pairs of one LFA launch)"
                    % ("cts_gemm_split_kernel" if split else
                       "cts_gemm_ov_kernel" if dtype != "fp32" and Cin in (64, 128, 256)
@@ -583,6 +654,7 @@ def main():
             "warmup": args.warmup,
             "spinup_steps": spinup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "us_per_step": elapsed / args.steps * 1e6,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -600,7 +672,13 @@ def main():
                                   "(host_format)",
                        "streams": ("LFA and decode on two streams" if hp.side is not None
                                    else "one stream"),
-                       "parallelism": "image-sharded x%d, no collective" % world},
+                       "gather": (("formatted lane lists (CULane text) of every %s step gathered on "
+                                   "rank 0 in image order by a host thread over gloo, inside the "
+                                   "timed region" % ("" if args.gather_every <= 1 else
+                                                     "%d-th" % args.gather_every))
+                                  if gather_thread is not None else
+                                  ("none (one rank)" if world == 1 else "off")),
+                       "parallelism": "image-sharded x%d, no collective on the data path" % world},
             "roofline": roof,
             "lfa_ms": lfa_ms,
             "decode_ms": dec_ms,
@@ -618,7 +696,7 @@ def main():
             reps = 20
             t0 = time.perf_counter()
             for _ in range(reps):
-                nl, nb = consume(slot)
+                nl, nb, _ = consume(slot)
             t_fmt = (time.perf_counter() - t0) / reps
             gpu_ips = B * args.steps / elapsed
             out["host_format"] = {
@@ -632,6 +710,14 @@ def main():
             }
             if args.consume:
                 out["host_format"]["lanes_in_timed_region"] = consumed[0]
+            if gather_thread is not None:
+                out["gather"] = {"steps": gathered["steps"], "images": gathered["images"],
+                                 "bytes": gathered["bytes"],
+                                 "bytes_per_step": gathered["bytes"] / max(1, gathered["steps"]),
+                                 "images_per_step": gathered["images"] / max(1, gathered["steps"]),
+                                 "lanes_per_step": gathered["lanes"] / max(1, gathered["steps"]),
+                                 "rank0_images_per_step": B,
+                                 "rank0_lanes_per_step": consumed[0] / max(1, args.steps)}
         if world == 1 and not args.no_cpu_baseline:
             # every core this process may use: its affinity mask, or what the box grants
             # through OMP_NUM_THREADS where that is smaller (nproc shows the whole machine)

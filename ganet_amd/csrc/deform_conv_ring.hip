@@ -191,7 +191,8 @@ __device__ __forceinline__ uint4 ring_entry(const A &a, int ho, int wo, int t, f
 
 // Timing experiments, compiled in by -DGANET_RING_ABLATE=<bits> (a separate library, see
 // ganet_amd/build.py): 1 nothing produced (no MFMA, no x load, no Y store), 2 nothing sampled,
-// 4 no waiting on the team's counter, 8 no weight staging.  Results are then undefined.
+// 4 no waiting on the team's counter, 8 no weight staging, 16 no image-edge work (sums not
+// stored, coordinates and x of the following images not fetched).  Results are then undefined.
 #ifndef GANET_RING_ABLATE
 #define GANET_RING_ABLATE 0
 #endif
@@ -487,12 +488,13 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
     //   3  vmcnt(8): everything this wave sent before those gathers is complete - the store of
     //      plane m-1, the weights it staged in step m-1 - then the workgroup's barrier; one lane
     //      adds the workgroup to the team's counter (ARRIVAL m: planes <= m-1 are stored, the
-    //      gathers of planes <= m-3 have returned)
-    //   4  plane m-2 is blended into the sums; plane m+2's weights go to the buffer plane m's
-    //      sat in; the next image's x is fetched where plane m was an image's last; at an
-    //      image's last tap the sums leave and the next image's coordinates are formed
+    //      gathers of planes <= m-3 have returned); plane m+2's weights go to the buffer plane
+    //      m's sat in (LDS-DMA); a look at the counter is sent
+    //   4  plane m-2 is blended into the sums; at an image's last tap the sums leave and the
+    //      next image's coordinates are formed
     //   5  once the counter shows arrival m of every workgroup - posted half a step ago - plane
-    //      m is stored into slot m % 3 (it held plane m-3) and step m+1 may gather plane m-1
+    //      m is stored into slot m % 3 (it held plane m-3) and step m+1 may gather plane m-1;
+    //      where plane m was an image's last, the next image's x is fetched
     u32x4 ypk[2];
     int t = 0, pair = 0;                     // tap and pair of plane m
     int tq = 0, pq = 0;                      // ... of plane m-1 (read from m = 1 on)
@@ -563,6 +565,13 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
         RING_WAIT_ALL();
       RING_BARRIER();
       if (tid == 0 && m >= 1) asm_atomic_inc(bar);
+      // every wave is past plane m's MFMAs: plane m+2's weights take the buffer (they have until
+      // the next step's barrier to land)
+      if (has_m && m + 2 < NP && !RABL(8)) stage_weights((t + 2) % T, m & 1);
+      // a look at the counter, sent now and read at the end of the step: by then it has come
+      // back, and it usually shows every workgroup's arrival m already
+      unsigned pv = 0;
+      if (lane == 0 && !dead && !RABL(4)) pv = rflag_load(bar);
 
       // ---- 4: blend plane m-2; an image's last tap closes it ------------------------------
       if (!RABL(2)) {
@@ -583,9 +592,7 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
           racc_piece<TA>(v[st][3], lh * lw * mk, oacc[st]);
         }
       }
-      // (behind the blend: beside an LDS-DMA in flight the compiler waits for every load at once)
-      if (has_m && m + 2 < NP && !RABL(8)) stage_weights((t + 2) % T, m & 1);
-      if (has_g && tg == T - 1) {
+      if (has_g && tg == T - 1 && !RABL(16)) {
         if (act_g) {
           store_out(image_of(pg));
           zero_out();
@@ -595,6 +602,8 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
       }
 
       // ---- 5: arrival m of every workgroup; plane m leaves for slot m % 3 ------------------
+      pv = (unsigned)rsgpr((int)pv);
+      if (pv > seen) seen = pv;
       if (m >= 1 && m <= NP) wait_count((unsigned)TEAM_WGS * (unsigned)m);
       if (act_m && !dead && y_ok) {
         const unsigned char *dst = ring + (size_t)(m % NSLOT) * slot_bytes;
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(RNT, 4) void lfa_ring_kernel(RingArgs a) {
       // ONE block: the compiler's wait bookkeeping merges paths, and a fetch in one conditional
       // block with its first use in another makes it wait for every load ahead of every step's
       // MFMAs, the gathers just sent included.
-      if (act_m && t == T - 1 && image_of(pair + 1) < B) {
+      if (act_m && t == T - 1 && image_of(pair + 1) < B && !RABL(16)) {
         load_x(image_of(pair + 1));
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(xb[ks]));

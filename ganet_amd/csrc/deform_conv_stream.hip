@@ -32,6 +32,13 @@
 // from counters.  Producing never waits and every resident workgroup has producing waves, so
 // every band a sampling wave waits for gets done whatever the placement; a producing wave
 // samples once no item of its kind is left.
+// The hand-off is NOT a release/acquire pair: the counter add and its poll are relaxed, and
+// what orders Y behind the flag is (a) the producer's s_waitcnt vmcnt(0) (its stores have been
+// acknowledged by the L2 both sides share), (b) the consumer issuing its loads of Y after the
+// poll returned (a compiler barrier keeps the order; the hardware returns a wave's loads in
+// order) and (c) no L1 holding an old copy (no line is loaded before it is complete).  A change
+// of any of the three needs the agent-scope forms; tests/test_gpu_dcn_algo3.py's bit-identity
+// with algorithm 2 is the gate.
 // Nothing depends on dispatch order.  What the launch needs is an XCD that holds workgroups
 // of every kind at once: owner words are only taken by such an XCD.  Every wait is bounded
 // (STREAM_TIMEOUT_TICKS); a timeout sets ctl[CTL_ERROR] and every wave leaves.

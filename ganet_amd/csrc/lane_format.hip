@@ -13,9 +13,11 @@
 // `int(v * ratio + offset)` as two rounded operations, a fused multiply-add would differ in
 // the last bit and with it the truncated integer.
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -96,6 +98,10 @@ inline bool cluster_coord(int32_t c, int downscale, const Scale &s, int32_t *out
 // `work` (points of the whole batch) below WORK_PER_THREAD a thread keeps the call serial
 constexpr long long WORK_PER_THREAD = 16384;
 
+// An exception inside f (a vector that cannot grow) must neither leave a worker thread - that
+// is std::terminate - nor unwind the caller past threads that are still joinable: every body
+// catches, every thread is joined, and the failure is thrown again on the calling thread, where
+// guarded() turns it into GANET_ERR_WORKSPACE like any other allocation failure.
 template <typename F>
 void for_images(int B, int threads, long long work, F f) {
   if ((long long)threads > work / WORK_PER_THREAD) threads = (int)(work / WORK_PER_THREAD);
@@ -103,22 +109,24 @@ void for_images(int B, int threads, long long work, F f) {
     for (int b = 0; b < B; ++b) f(b);
     return;
   }
-  std::vector<std::thread> pool;
-  pool.reserve(threads);
-  int started = 0;
-  for (; started < threads; ++started) {
-    const int t = started;
+  std::atomic<bool> failed(false);
+  auto stripe = [&](int t) {
     try {
-      pool.emplace_back([=]() {
-        for (int b = t; b < B; b += threads) f(b);
-      });
-    } catch (...) {   // no more threads to be had: the calling thread takes the rest
-      break;
+      for (int b = t; b < B && !failed.load(std::memory_order_relaxed); b += threads) f(b);
+    } catch (...) {
+      failed.store(true, std::memory_order_relaxed);
     }
+  };
+  std::vector<std::thread> pool;
+  int started = 0;
+  try {
+    pool.reserve(threads);
+    for (; started < threads; ++started) pool.emplace_back(stripe, started);
+  } catch (...) {   // no more threads to be had: the calling thread takes the rest
   }
-  for (int t = started; t < threads; ++t)
-    for (int b = t; b < B; b += threads) f(b);
+  for (int t = started; t < threads; ++t) stripe(t);
   for (auto &th : pool) th.join();
+  if (failed.load()) throw std::bad_alloc();
 }
 
 // decimal text of an int followed by ".00": what "{:.2f}".format(int) prints

@@ -103,7 +103,7 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
     (GANET_DCN_ALGO_KEEP_Y) it gets keep_y["y"] = that float32 tensor (a view of the call's
     workspace) for deform_conv_backward(..., y_saved=...), otherwise it stays empty.
     check=True synchronises and raises if the algorithm left a failure word in its
-    workspace (algorithm 3 only: ganet_deform_conv_status_offset)."""
+    workspace (algorithms 3 and 4: ganet_deform_conv_status_offset)."""
     if not input.is_cuda:
         raise NotImplementedError
     if input.dtype not in _DTYPES:
@@ -202,8 +202,9 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
         if off != ctypes.c_size_t(-1).value:
             word = int(ws[off:off + 4].view(torch.int32).item())   # synchronises
             if word != 0:
-                raise RuntimeError("ganet_deform_conv_forward: algorithm 3 gave up waiting "
-                                   "(status word %d); the output is invalid" % word)
+                raise RuntimeError("ganet_deform_conv_forward: the persistent launch (algorithm "
+                                   "3 / 4) gave up waiting (status word %d); the output is "
+                                   "invalid" % word)
     return out
 
 

@@ -34,34 +34,38 @@ import numpy as np
 from . import _lib
 
 
-def adjust_result(lanes, centers, crop_bbox, img_shape, points_thr):
-    h_img, w_img = img_shape[:2]
-    ratio_x = (crop_bbox[2] - crop_bbox[0]) / w_img
-    ratio_y = (crop_bbox[3] - crop_bbox[1]) / h_img
-    offset_x, offset_y = crop_bbox[:2]
+class _CropMap(object):
+    """Heat-map-scaled (x, y) -> pixel of the original frame: v * ratio + offset per axis, then
+    Python's int() (truncation towards zero, errors on NaN / infinity kept)."""
 
-    results, virtual_centers, cluster_centers = [], [], []
-    if lanes is not None:
-        for lane in lanes:
-            pts, cts = [], []
-            for pt in lane['points']:
-                pt[0] = int(pt[0] * ratio_x + offset_x)
-                pt[1] = int(pt[1] * ratio_y + offset_y)
-                pts.append(tuple(pt))
-            for ct in lane['centers']:
-                ct[0] = int(ct[0] * ratio_x + offset_x)
-                ct[1] = int(ct[1] * ratio_y + offset_y)
-                cts.append(tuple(ct))
-            if len(pts) > points_thr:
-                results.append(pts)
-                virtual_centers.append(cts)
-    if centers is not None:
-        for center in centers:
-            c = center['center']
-            c[0] = int(c[0] * ratio_x + offset_x)
-            c[1] = int(c[1] * ratio_y + offset_y)
-            cluster_centers.append(tuple(c))
-    return results, virtual_centers, cluster_centers
+    def __init__(self, crop_bbox, img_shape):
+        x0, y0, x1, y1 = crop_bbox[:4]
+        height, width = img_shape[:2]
+        self.scale = ((x1 - x0) / width, (y1 - y0) / height)
+        self.shift = (x0, y0)
+
+    def move(self, xy):
+        """Rewrites the mutable pair `xy` in place, as the reference does, and returns it as a
+        tuple."""
+        for axis in (0, 1):
+            xy[axis] = int(xy[axis] * self.scale[axis] + self.shift[axis])
+        return tuple(xy)
+
+
+def adjust_result(lanes, centers, crop_bbox, img_shape, points_thr):
+    """tools/ganet/culane/test_dataset.py:79-113 (== tusimple/test_dataset.py:49-83): same
+    arguments, same three result lists, same in-place rewrite of the coordinates inside `lanes`
+    and `centers`; lanes of more than `points_thr` points are kept, with their start points."""
+    to_frame = _CropMap(crop_bbox, img_shape)
+    kept_points, kept_starts = [], []
+    for lane in (lanes if lanes is not None else ()):
+        moved = [to_frame.move(p) for p in lane['points']]
+        starts = [to_frame.move(c) for c in lane['centers']]
+        if len(moved) > points_thr:
+            kept_points.append(moved)
+            kept_starts.append(starts)
+    cluster = [to_frame.move(entry['center']) for entry in (centers if centers is not None else ())]
+    return kept_points, kept_starts, cluster
 
 
 def _scalar_dtype(sample, ratio):

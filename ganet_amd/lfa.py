@@ -10,7 +10,6 @@ The reference runs an elementwise subtract kernel, the deform-conv op and a
 ReLU kernel; here the subtraction happens while the sampling coordinates are
 formed and the ReLU in the contraction's epilogue.
 """
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -20,11 +19,13 @@ from .dcn import DeformConv1D, _keep_holder, deform_conv_backward, deform_conv_f
 
 
 def dcn_base_offset(num_points, dtype=torch.float32, device=None):
-    """[0,-p, 0,-p+1, ..., 0,+p] shaped [1, 2K, 1, 1] (lanepoints_conv.py:63-74)."""
-    pad = int((num_points - 1) / 2)
-    base = np.arange(-pad, pad + 1).astype(np.float64)
-    off = np.stack([np.repeat(0, num_points), np.tile(base, 1)], axis=1).reshape(-1)
-    return torch.tensor(off).reshape(1, -1, 1, 1).to(dtype=dtype, device=device)
+    """The 1 x K kernel grid DeformConv1D adds to its offsets, as (dy, dx) pairs per tap:
+    dy = 0, dx = tap - (K - 1) // 2, shaped [1, 2K, 1, 1] (what lanepoints_conv.py:63-74
+    builds and :170 subtracts from the regressed points)."""
+    half = (num_points - 1) // 2
+    grid = torch.zeros(num_points, 2, dtype=torch.float64)
+    grid[:, 1] = torch.arange(-half, half + 1, dtype=torch.float64)
+    return grid.reshape(1, 2 * num_points, 1, 1).to(dtype=dtype, device=device)
 
 
 class _FusedLfaTail(Function):

@@ -56,8 +56,11 @@ class HotPath(object):
                 raise ValueError("unsupported LFA configuration")
             self.packed = torch.empty(nb, dtype=torch.uint8, device=self.device)
             self.ws_bytes = self.L.ganet_deform_conv_workspace_bytes(ctypes.byref(p))
-            # 1 = fused sample-then-contract kernel, 2 = contract-then-sample pair
+            # 1 = fused sample-then-contract kernel, 2 = contract-then-sample pair, 3 / 4 = that
+            # pair as one persistent launch (both leave a status word in the workspace)
             self.lfa_algorithm = self.L.ganet_deform_conv_algorithm(ctypes.byref(p))
+            off = self.L.ganet_deform_conv_status_offset(ctypes.byref(p))
+            self._status_off = None if off == ctypes.c_size_t(-1).value else off
             self.ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8,
                                   device=self.device)
             self.feature = torch.empty(
@@ -131,6 +134,23 @@ class HotPath(object):
             self.ws_bytes, stream)
         _lib.check(rc, "ganet_deform_conv_forward")
         return self.feature
+
+    def lfa_status(self):
+        """The status word of the persistent LFA launches (algorithms 3 and 4), 0 for the other
+        algorithms.  Synchronises the device.  Non-zero: a bounded wait inside the launch ran out
+        (the GPU could not keep its workgroups resident, e.g. beside other streams' kernels) and
+        `feature` is invalid."""
+        if self._status_off is None:
+            return 0
+        torch.cuda.synchronize(self.device)
+        return int(self.ws[self._status_off:self._status_off + 4].view(torch.int32).item())
+
+    def check_lfa(self):
+        """Raises if the last LFA call left a failure word (see lfa_status)."""
+        word = self.lfa_status()
+        if word != 0:
+            raise RuntimeError("the persistent LFA launch (algorithm %d) gave up waiting (status "
+                               "word %d): its output is invalid" % (self.lfa_algorithm, word))
 
     def decode(self, heat, offset, error, copy_to_host=True):
         """Enqueue decode + grouping on the current stream, then the D2H copy of
@@ -236,6 +256,7 @@ class HotPath(object):
                 self.copy_stream.synchronize()
             if self.side is not None:
                 self.side.synchronize()
+            self.check_lfa()            # (algorithms 3 and 4 only; free for the others)
             slot = self.last
         else:
             slot["ready"].synchronize()

@@ -40,6 +40,31 @@ def gather_lane_lists(local_lists, dst=0, group=None):
     return out
 
 
+def gather_text_blocks(text, lengths, dst=0, group=None):
+    """Gather every rank's formatted result block on rank `dst`, in image order.
+
+    `text`: the bytes of this rank's images back to back (e.g. the CULane `.lines.txt` texts
+    of formats.BatchLanes.culane_text_buffer, image b's text being `lengths[b]` bytes long);
+    `lengths`: one entry per image of the rank's block.  Returns (bytes, lengths) of all
+    images on `dst` - rank 0's block first, then rank 1's, ...: the order of shard_range -
+    and None elsewhere.  Host objects only (the reference gathers pickled result lists the same
+    way, mmdet/apis/test.py:122-166); give it a gloo group when the default one is RCCL so that
+    the GPUs' streams are not involved."""
+    lengths = [int(n) for n in lengths]
+    text = bytes(text)
+    if sum(lengths) != len(text):
+        raise ValueError("lengths do not add up to the text")
+    if not dist.is_available() or not dist.is_initialized():
+        return text, lengths
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object((text, lengths), gathered, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return b"".join(g[0] for g in gathered), [n for g in gathered for n in g[1]]
+
+
 def run_sharded(process_block, n_images, group=None, dst=0):
     """Run `process_block(lo, hi) -> list` on this rank's block and gather."""
     if dist.is_available() and dist.is_initialized():

@@ -337,7 +337,9 @@ int ganet_decode_batch(const float *heat, const float *offset,
  * <= GANET_DECODE_NOALLOC_MAX_BYTES, else GANET_ERR_WORKSPACE.  Every call on one GPU
  * shares that GPU's array: calls that overlap on one GPU (two streams, two threads)
  * race; run them one after the other on one stream.  Results are identical to
- * ganet_decode_batch. */
+ * ganet_decode_batch.  The FIRST call on a GPU looks the array's address up
+ * (hipGetSymbolAddress, which may load the code object): make one call per GPU outside any
+ * graph capture before capturing it. */
 #define GANET_DECODE_NOALLOC_MAX_BYTES (4u << 20)
 int ganet_decode_batch_noalloc(const float *heat, const float *offset,
                                const float *error, const ganet_decode_params *p,

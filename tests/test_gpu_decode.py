@@ -83,6 +83,8 @@ def test_reference_call_sequence(name):
 
 @pytest.mark.parametrize("shape,B,by_center", [("s8_culane", 128, True),
                                                ("s4_culane", 32, True),
+                                               ("s4_culane", 128, True),   # C4's per-GPU share at 8 GPUs
+                                               ("dense_s4", 4, True),
                                                ("dense_s8", 8, True),
                                                ("s8_tusimple", 16, False)])
 def test_batch_against_oracle(shape, B, by_center):

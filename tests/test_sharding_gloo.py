@@ -75,3 +75,43 @@ def test_two_ranks_gather_equals_single_process():
     want = _lanes_of_block(0, B, B)
     assert [g[0] for g in got] == list(range(B))
     assert got == want
+
+
+def _text_worker(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(B, rank, world)
+        texts = [("image %d\n" % b * (b % 3)).encode() for b in range(lo, hi)]   # some are empty
+        res = sharding.gather_text_blocks(b"".join(texts), [len(t) for t in texts])
+        if rank == 0:
+            q.put(res)
+        else:
+            assert res is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_text_blocks_are_gathered_in_image_order():
+    """What bench.py --gpus N does with every step's formatted lane lists: rank 0 ends up with
+    the texts of all images, rank 0's block first (the order of shard_range)."""
+    B, world = 11, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_text_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    text, lengths = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = [("image %d\n" % b * (b % 3)).encode() for b in range(B)]
+    assert lengths == [len(t) for t in want]
+    assert text == b"".join(want)
+    with pytest.raises(ValueError):
+        sharding.gather_text_blocks(b"abc", [1, 1])
+    # no process group: the local block comes back as it is
+    assert sharding.gather_text_blocks(b"abc", [1, 2]) == (b"abc", [1, 2])

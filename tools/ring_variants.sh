@@ -5,16 +5,13 @@
 set -e
 cd "$(dirname "$0")/.."
 ROWS=(
-  "-DGANET_RING_GATHER_AUX=0"
-  "-DGANET_RING_GATHER_AUX=2"
-  "-DGANET_RING_GATHER_AUX=17"
-  "-DGANET_RING_GATHER_AUX=18"
+  "-DGANET_RING_ABLATE=27"
+  "-DGANET_RING_ABLATE=19"
+  "-DGANET_RING_ABLATE=3"
   "-DGANET_RING_ABLATE=1"
   "-DGANET_RING_ABLATE=2"
-  "-DGANET_RING_ABLATE=3"
-  "-DGANET_RING_ABLATE=11"
   "-DGANET_RING_ABLATE=4"
-  "-DGANET_RING_ABLATE=8"
+  "-DGANET_RING_GATHER_AUX=0"
 )
 if [ "$1" = build ]; then
   for r in "${ROWS[@]}"; do GANET_RING_DEFS="$r" python -m ganet_amd.build | tail -1; done
