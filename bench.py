@@ -472,7 +472,13 @@ def main():
     gathered = {"steps": 0, "images": 0, "bytes": 0, "lanes": 0, "error": None}
     if dist is not None and world > 1 and wl["decode"] and not args.no_gather and not args.graph:
         import queue
-        gather_group = dist.new_group(backend="gloo") if backend != "gloo" else None
+        from ganet_amd import sharding as _sh
+        # one node (the driver's case): shared-memory rings; ranks on several nodes: a gloo group
+        one_node = int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world
+        if one_node and not os.environ.get("GANET_BENCH_GATHER_GLOO"):
+            gather_group = _sh.NodeGather(rank, world, os.environ.get("MASTER_PORT", "0"))
+        else:
+            gather_group = dist.new_group(backend="gloo") if backend != "gloo" else None
         gather_q = queue.Queue()
 
     def gather_loop():
@@ -482,7 +488,10 @@ def main():
                 item = gather_q.get()
                 if item is None:
                     return
-                res = sharding.gather_text_blocks(item[0], item[1], dst=0, group=gather_group)
+                if isinstance(gather_group, sharding.NodeGather):
+                    res = gather_group.gather(item[0], item[1])
+                else:
+                    res = sharding.gather_text_blocks(item[0], item[1], dst=0, group=gather_group)
                 if res is not None:
                     gathered["steps"] += 1
                     gathered["images"] += len(res[1])
@@ -673,8 +682,8 @@ def main():
                        "streams": ("LFA and decode on two streams" if hp.side is not None
                                    else "one stream"),
                        "gather": (("formatted lane lists (CULane text) of every %s step gathered on "
-                                   "rank 0 in image order by a host thread over gloo, inside the "
-                                   "timed region" % ("" if args.gather_every <= 1 else
+                                   "rank 0 in image order by a host thread (shared-memory rings within "
+                                   "the node, gloo across nodes), inside the timed region" % ("" if args.gather_every <= 1 else
                                                      "%d-th" % args.gather_every))
                                   if gather_thread is not None else
                                   ("none (one rank)" if world == 1 else "off")),

@@ -115,3 +115,45 @@ def test_text_blocks_are_gathered_in_image_order():
         sharding.gather_text_blocks(b"abc", [1, 1])
     # no process group: the local block comes back as it is
     assert sharding.gather_text_blocks(b"abc", [1, 2]) == (b"abc", [1, 2])
+
+
+def _node_worker(rank, world, key, B, steps, q, block_bytes):
+    g = sharding.NodeGather(rank, world, key, block_bytes=block_bytes, slots=4)
+    try:
+        got = []
+        for step in range(steps):
+            lo, hi = sharding.shard_range(B, rank, world)
+            texts = [("s%d i%d\n" % (step, b) * (b % 3)).encode() for b in range(lo, hi)]
+            res = g.gather(b"".join(texts), [len(t) for t in texts])
+            assert (res is None) == (rank != 0)
+            if rank == 0:
+                got.append(res)
+        if rank == 0:
+            q.put(got)
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("block_bytes", [1 << 16, 48])
+def test_node_gather_keeps_image_order(block_bytes):
+    """bench.py's transport on one node: three ranks, more steps than a ring has slots (so the
+    credits are exercised), rank 0 gets every step's blocks in image order; no process group
+    involved.  With 48-byte slots some blocks fit their ring and some travel through the socket."""
+    B, world, steps = 11, 3, 19
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = "t%d_%d" % (os.getpid(), block_bytes)
+    procs = [ctx.Process(target=_node_worker, args=(r, world, key, B, steps, q, block_bytes))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for step, (text, lengths) in enumerate(got):
+        want = [("s%d i%d\n" % (step, b) * (b % 3)).encode() for b in range(B)]
+        assert lengths == [len(t) for t in want]
+        assert text == b"".join(want)
+    solo = sharding.NodeGather(0, 1, "x")
+    assert solo.gather(b"ab", [2]) == (b"ab", [2])
