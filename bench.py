@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--device-pack", action="store_true",
                     help="pack in device memory and copy D2H (default: the pack kernel "
                          "writes the pinned host block directly)")
+    ap.add_argument("--graph-fork", action="store_true",
+                    help="with --graph: record the LFA and the decode as two branches of the graph "
+                         "(measured slower at batch 1)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step in a HIP graph and replay it (small batches: "
                          "removes the host launch cost)")
@@ -442,9 +445,14 @@ def main():
             one_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            one_step()
+        if wl["decode"]:
+            # --graph-fork: the LFA and the decode as two branches of the graph
+            graph = hp.capture(d["x"], d["pts"], d["heat"], d["off"], d["err"],
+                               fork=args.graph_fork)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one_step()
         graph.replay()
         torch.cuda.synchronize()
     if wl["decode"]:
@@ -680,6 +688,8 @@ def main():
                                   "records land in pinned host memory; formatting timed beside "
                                   "(host_format)",
                        "streams": ("LFA and decode on two streams" if hp.side is not None
+                                   else "LFA and decode as two branches of the graph"
+                                   if graph is not None and wl["decode"] and args.graph_fork
                                    else "one stream"),
                        "gather": (("formatted lane lists (CULane text) of every %s step gathered on "
                                    "rank 0 in image order by a host thread (shared-memory rings within "

@@ -33,7 +33,8 @@ EXPORTS = (
     "ganet_decode_pack", "ganet_deform_conv_algorithm", "ganet_deform_conv_status_offset",
     "ganet_deform_conv_y_offset", "ganet_deform_conv_backward_y",
     "ganet_deform_conv_backward_workspace_bytes", "ganet_deform_conv_backward",
-    "ganet_decode_batch_noalloc",
+    "ganet_decode_batch_noalloc", "ganet_decode_packed_workspace_bytes",
+    "ganet_decode_batch_packed",
     "ganet_lanes_from_packed", "ganet_tusimple_from_lanes", "ganet_culane_text",
 )
 
@@ -145,6 +146,13 @@ def lib():
         L.ganet_decode_pack.argtypes = [ctypes.POINTER(DecodeParams),
                                        ctypes.POINTER(DecodeOut), ctypes.c_void_p,
                                        ctypes.c_size_t, ctypes.c_void_p]
+        L.ganet_decode_packed_workspace_bytes.restype = ctypes.c_size_t
+        L.ganet_decode_packed_workspace_bytes.argtypes = [ctypes.POINTER(DecodeParams)]
+        L.ganet_decode_batch_packed.restype = ctypes.c_int
+        L.ganet_decode_batch_packed.argtypes = [
+            ctypes.c_void_p] * 3 + [ctypes.POINTER(DecodeParams), ctypes.POINTER(DecodeOut),
+                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                    ctypes.c_size_t, ctypes.c_void_p]
         L.ganet_lanes_from_packed.restype = ctypes.c_int
         L.ganet_lanes_from_packed.argtypes = [
             ctypes.c_void_p, ctypes.POINTER(LaneFormat), ctypes.c_void_p, ctypes.c_size_t,

@@ -31,9 +31,8 @@ def _newer(a, b):
 def _variant_flags():
     """Extra -D flags of the profiling / debug builds asked for through the environment."""
     extra = ["-DGANET_ABLATE"] if os.environ.get("GANET_ABLATE") else []  # profiling build
-    if os.environ.get("GANET_RING_DEBUG"):
-        extra.append("-DGANET_RING_DEBUG")
-    extra += os.environ.get("GANET_RING_DEFS", "").split()
+    extra += os.environ.get("GANET_RING_DEFS", "").split()      # -DGANET_RING_... (ablations)
+    extra += os.environ.get("GANET_DECODE_DEFS", "").split()    # -DGANET_DECODE_STAMPS
     if os.environ.get("GANET_STREAM_DEBUG"):
         extra.append("-DGANET_STREAM_DEBUG")
         extra += os.environ.get("GANET_STREAM_DEFS", "").split()
@@ -41,8 +40,8 @@ def _variant_flags():
 
 
 def build_lib(force=False, verbose=False):
-    """The product library; with variant flags in the environment (GANET_ABLATE, GANET_RING_DEBUG,
-    GANET_RING_DEFS, GANET_STREAM_DEBUG) a SEPARATE library libganet_hip_<tag>.so with objects of
+    """The product library; with variant flags in the environment (GANET_ABLATE, GANET_RING_DEFS,
+    GANET_DECODE_DEFS, GANET_STREAM_DEBUG) a SEPARATE library libganet_hip_<tag>.so with objects of
     its own, so that a debug or ablation build can never be picked up as the product library
     afterwards (load it with GANET_HIP_LIB=<path>)."""
     global LIB, OBJ_DIR
@@ -65,7 +64,8 @@ def build_lib(force=False, verbose=False):
         return LIB
     objs, relink = [], force or not os.path.exists(LIB)
     # flags named after one source file only rebuild that file; the rest are the product's objects
-    only = {"-DGANET_RING": "deform_conv_ring.hip", "-DGANET_STREAM": "deform_conv_stream.hip"}
+    only = {"-DGANET_RING": "deform_conv_ring.hip", "-DGANET_STREAM": "deform_conv_stream.hip",
+            "-DGANET_DECODE": "decode.hip"}
     touched = {v for f in extra for k, v in only.items() if f.startswith(k)}
     narrow = bool(extra) and all(any(f.startswith(k) for k in only) for f in extra)
     if narrow:

@@ -30,6 +30,8 @@
 
 #include "common.h"
 
+#include <cmath>
+#include <limits>
 #include <mutex>
 
 namespace {
@@ -104,16 +106,25 @@ __global__ __launch_bounds__(kBlock) void decode_mask_kernel(
     kmask[(size_t)b * nwords + word] = m;
 }
 
+// Wavefront scan / reduction on the DPP path (row shifts inside the 16-lane rows, then the two
+// row broadcasts of GFX9): six VALU instructions instead of six trips through the LDS
+// crossbar (ds_bpermute), which is what a __shfl costs.
+template <typename OP>
+__device__ __forceinline__ int wave_scan_dpp(int v, int identity, OP op) {
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+  return v;   // inclusive over lanes 0..lane
+}
+
 // Exclusive scan of one int per thread over the 256-thread block.
 __device__ __forceinline__ int block_excl_scan(int v, int *wave_sums,
                                                int *total) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
-  }
+  const int incl = wave_scan_dpp(v, 0, [](int a, int b) { return a + b; });
   if (lane == 63) wave_sums[wid] = incl;
   __syncthreads();
   int off = 0, tot = 0;
@@ -129,10 +140,40 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wave_sums,
 }
 
 __device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
+  v = wave_scan_dpp(v, INT_MAX, [](int a, int b) { return min(a, b); });
+  return __builtin_amdgcn_readlane(v, 63);
 }
+
+// `sqrt(u) <= T` decided without the square root.  The correctly rounded square root is
+// monotone, so the u >= 0 that pass are exactly the doubles up to one bound; the bound is found
+// once per call on the host (T*T, then a step or two along the doubles, with the same IEEE
+// sqrt), so every decision is the one `sqrt(u) <= T` makes - NaN and infinite u included.
+// -1: nothing passes (T negative or NaN).
+double sqrt_le_bound(double T) {
+  if (!(T >= 0.0)) return -1.0;
+  if (std::isinf(T)) return T;
+  double u = T * T;
+  if (std::isinf(u)) u = std::numeric_limits<double>::max();
+  while (u > 0.0 && std::sqrt(u) > T) u = std::nextafter(u, 0.0);
+  for (;;) {
+    const double n = std::nextafter(u, std::numeric_limits<double>::infinity());
+    if (!(std::sqrt(n) <= T)) break;
+    u = n;
+  }
+  return u;
+}
+
+#ifdef GANET_DECODE_STAMPS   // profiling build only (tools/decode_stamps.py): phase times of image 0
+__device__ unsigned long long g_decode_stamps[16];
+#define DSTAMP(i)                                                            \
+  do {                                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_decode_stamps[i] = wall_clock64(); \
+  } while (0)
+#else
+#define DSTAMP(i) \
+  do {            \
+  } while (0)
+#endif
 
 struct DecodeArgs {
   const float *heat, *offset, *error;
@@ -141,8 +182,15 @@ struct DecodeArgs {
   int H, W, nwords;
   float root_thr;
   double cluster_thr, by_center_thr;
+  double cluster_sq, by_center_sq;   // sqrt_le_bound of the two: `d <= thr` as `d*d <= .._sq`
   int max_kpts, max_centers, max_groups, flags;
   ganet_decode_out out;
+  // ganet_decode_batch_packed, one-workgroup form: the record stream of ganet_decode_pack is
+  // written by the group kernel itself (nullptr: not)
+  int32_t *packed;
+  long long packed_words;
+  unsigned long long *pack_ctr;      // [0] words handed out so far, [1] images finished
+  int B;
 };
 
 // Large images (by-centre grouping): the keypoint lists of the whole batch on a grid of
@@ -225,6 +273,7 @@ __global__ __launch_bounds__(kBlock) void decode_assign_kernel(DecodeArgs a) {
   const int ng = min(o_counts[2], a.max_groups);   // more groups: flagged as overflow
   if ((int)blockIdx.x * kBlock >= nk_st) return;    // uniform
   const double T = a.by_center_thr;
+  const double U = a.by_center_sq;
   const bool nearest = (a.flags & 4) != 0;
   const int i = blockIdx.x * kBlock + tid;
   const bool live = i < nk_st;
@@ -243,7 +292,12 @@ __global__ __launch_bounds__(kBlock) void decode_assign_kernel(DecodeArgs a) {
       if (found >= 0 && !nearest) break;
       const double dx = rx - (double)s_gx[g];
       const double dy = ry - (double)s_gy[g];
-      const double d = sqrt(dx * dx + dy * dy);
+      const double ss = dx * dx + dy * dy;
+      if (!nearest) {
+        if (ss <= U) found = g0 + g;      // = sqrt(ss) <= T
+        continue;
+      }
+      const double d = sqrt(ss);
       if (d <= T && (found < 0 || d < best)) {
         found = g0 + g;
         best = d;
@@ -265,6 +319,19 @@ __global__ __launch_bounds__(kBlock) void decode_assign_kernel(DecodeArgs a) {
   }
 }
 
+// The record stream written from inside decode_group_kernel<0> (DecodeArgs::packed).  Same
+// header and record layout as decode_pack_kernel below, but a record's place in the stream is
+// handed out by an atomic counter when the image's sizes are known, so records follow one
+// another in the order the images got there - readers go by the header's offsets - and the
+// words are stored where they are produced: no second launch, no second pass over the lists.
+// The last workgroup to finish writes the total and leaves both counters at zero for the next
+// call on this workspace.
+struct RecordSlot {
+  int32_t *r;        // the image's record, nullptr: no stream asked for or the record does not fit
+  int off, words;    // header words 4 and 5
+  bool fits;
+};
+
 // MODE 0: build the keypoint / centre lists from the bitmap (steps 1-2), group, assign.
 // MODE 1: the lists already sit in the output arrays (ganet_group_batch).
 // MODE 2: large images - decode_gather_kernel wrote the keypoints and the unsorted centre
@@ -276,6 +343,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
   __shared__ int smem[6 * kMaxCenters];
   __shared__ int wave_sums[kWavesPerBlock];
   __shared__ int s_nc, s_ng;
+  __shared__ unsigned long long s_rec;
   __shared__ unsigned long long s_mask[DECODE ? kFusedMaskWords : 1];
   __shared__ __attribute__((aligned(16))) float s_heat[DECODE ? kFusedMaskWords * 64 : 1];
 
@@ -311,6 +379,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     s_ng = 0;
   }
   __syncthreads();
+  DSTAMP(0);
 
   int nk = 0, nc_found = 0, nk_st = 0, nc = 0, overflow = 0;
   if constexpr (DECODE) {
@@ -344,19 +413,63 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       for (int p = tid; p < (int)HW; p += kBlock)
         s_heat[p] = logits ? heat_prob(hb[p]) : hb[p];
     }
+    if (!(a.flags & 2)) {
+      // the reference's 1x3 window: 16 consecutive pixels per thread and pass (18 values read
+      // at once, one division), their 16 bits OR-ed into the bitmap - the decisions of
+      // heat_nms, without its branches
+      unsigned int *m32 = reinterpret_cast<unsigned int *>(s_mask);
+      for (int w = tid; w < 2 * a.nwords; w += kBlock) m32[w] = 0u;
+      __syncthreads();            // (also: the heat plane is in LDS)
+      DSTAMP(1);
+      const int nchunk = ((int)HW + 15) >> 4;
+      for (int c = tid; c < nchunk; c += kBlock) {
+        const int p0 = c << 4;
+        float v[18];
+        const float4 *q = reinterpret_cast<const float4 *>(s_heat + p0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 t = q[k];
+          v[1 + 4 * k] = t.x;
+          v[2 + 4 * k] = t.y;
+          v[3 + 4 * k] = t.z;
+          v[4 + 4 * k] = t.w;
+        }
+        v[0] = s_heat[p0 > 0 ? p0 - 1 : 0];
+        v[17] = s_heat[min(p0 + 16, kFusedMaskWords * 64 - 1)];
+        int x = p0 % W;
+        unsigned int bits = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          // heat_nms's running maximum m (take v when v > m or v is NaN) ends equal to h
+          // exactly when h >= both neighbours inside the row and none of the three is NaN
+          // (a NaN makes m NaN or a comparison false; -0 == +0 either way), so `m == h` is
+          // these two comparisons, with a neighbour outside the row standing at -inf
+          const float h = v[j + 1];
+          const float l = (x == 0) ? -INFINITY : v[j];
+          const float r = (x == W - 1) ? -INFINITY : v[j + 2];
+          const float keep = (h >= l && h >= r) ? 1.0f : 0.0f;
+          if (p0 + j < (int)HW && h * keep > a.kpt_thr) bits |= 1u << j;
+          x = (x + 1 == W) ? 0 : x + 1;
+        }
+        if (bits) atomicOr(&m32[c >> 1], bits << ((c & 1) << 4));
+      }
+    } else {
     __syncthreads();
+    DSTAMP(1);
     for (int p0 = 0; p0 < (int)HW; p0 += kBlock) {
       const int idx = p0 + tid;
       bool is_kpt = false;
       if (idx < (int)HW) {
         const int y = idx / W;
         const int x = idx - y * W;
-        is_kpt = heat_nms<false>(s_heat, a.H, W, y, x, (a.flags & 2) != 0) > a.kpt_thr;
+        is_kpt = heat_nms<false>(s_heat, a.H, W, y, x, true) > a.kpt_thr;
       }
       const unsigned long long m = __ballot(is_kpt);
       if (lane == 0 && (idx >> 6) < a.nwords) s_mask[idx >> 6] = m;
     }
+    }
     __syncthreads();
+    DSTAMP(2);
   }
   if (fused_mask) {
     // ---- 1a. small images: ordered compaction of the pixel indices into LDS (the
@@ -377,6 +490,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       }
     }
     __syncthreads();
+    DSTAMP(3);
     for (int pos = tid; pos < nk; pos += kBlock) {
       const int idx = s_kidx[pos];
       const int y = idx / W, x = idx - y * W;
@@ -431,6 +545,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     }
   }
   __syncthreads();
+  DSTAMP(4);
   nc_found = s_nc;
   nk_st = min(nk, a.max_kpts);
   nc = min(nc_found, min(a.max_centers, kMaxCenters));
@@ -448,6 +563,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     ckey[rank] = ki;
   }
   __syncthreads();
+  DSTAMP(5);
   for (int i = tid; i < nc; i += kBlock) {
     o_cxy[2 * i] = (int)(ckey[i] >> 16);
     o_cxy[2 * i + 1] = (int)(ckey[i] & 0xffffu);
@@ -485,13 +601,53 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     __syncthreads();
   }
   int ng = 0;
+  RecordSlot rec = {nullptr, 0, 0, true};
+  // block-uniform; called once, when the number of groups is known
+  auto take_record = [&](int ng_now) {
+    if constexpr (DECODE) {
+      if (!a.packed) return;
+      const int ngs = min(ng_now, a.max_groups);
+      rec.words = 7 * nk_st + 3 * nc + (a.by_center_thr >= 0 ? 2 * ngs : 0) + ngs;
+      if (tid == 0) s_rec = atomicAdd(a.pack_ctr, (unsigned long long)rec.words);
+      __syncthreads();
+      const unsigned long long off = s_rec;
+      rec.fits = (unsigned long long)a.B * 8 + off + (unsigned long long)rec.words <=
+                 (unsigned long long)a.packed_words;
+      rec.off = (int)(off < 0x7fffffffull ? off : 0x7fffffffull);
+      rec.r = rec.fits ? a.packed + (size_t)a.B * 8 + off : nullptr;
+    }
+  };
+  // keypoint i of the record: the lists were stored by this workgroup before a barrier
+  auto put_kpt = [&](int i, int gid) {
+    const int2 xy = *reinterpret_cast<const int2 *>(o_kxy + 2 * i);
+    const int2 al = *reinterpret_cast<const int2 *>(o_align + 2 * i);
+    const int2 rt = *reinterpret_cast<const int2 *>(o_root + 2 * i);
+    int32_t *r = rec.r;
+    r[2 * i] = xy.x;
+    r[2 * i + 1] = xy.y;
+    r[2 * nk_st + 2 * i] = al.x;
+    r[2 * nk_st + 2 * i + 1] = al.y;
+    r[4 * nk_st + 2 * i] = rt.x;
+    r[4 * nk_st + 2 * i + 1] = rt.y;
+    r[6 * nk_st + i] = gid;
+  };
   if (a.flags & 1) {
     // decode only
+    take_record(0);
+    if (rec.r) {
+      for (int i = tid; i < nk_st; i += kBlock) put_kpt(i, -1);
+      for (int i = tid; i < nc; i += kBlock) {
+        rec.r[7 * nk_st + 2 * i] = o_cxy[2 * i];
+        rec.r[7 * nk_st + 2 * i + 1] = o_cxy[2 * i + 1];
+        rec.r[7 * nk_st + 2 * nc + i] = o_cgid[i];
+      }
+    }
   } else if (a.by_center_thr >= 0) {
     // ---- 3. greedy clustering of the centres (post_process.py:160-165) ----
     // search_groups returns the first group holding ANY member within thr,
     // i.e. the smallest group index among earlier centres within thr.
     const double T = a.by_center_thr;
+    const double U = a.by_center_sq;
     if (wid == 0) {
       int ngl = 0;
       for (int i = 0; i < nc; ++i) {
@@ -502,8 +658,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
           const unsigned int kj = ckey[j];
           const double dx = (double)(xi - (int)(kj >> 16));
           const double dy = (double)(yi - (int)(kj & 0xffffu));
-          const double d = sqrt(dx * dx + dy * dy);  // exact integer operand
-          if (d <= T) best = min(best, (int)cgid[j]);
+          if (dx * dx + dy * dy <= U) best = min(best, (int)cgid[j]);   // = sqrt(.) <= T
         }
         best = wave_min(best);
         const int g = (best == INT_MAX) ? ngl++ : best;
@@ -512,7 +667,12 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       if (lane == 0) s_ng = ngl;
     }
     __syncthreads();
+    DSTAMP(6);
     ng = s_ng;
+    take_record(ng);
+    DSTAMP(7);
+    int32_t *const rc_ = rec.r ? rec.r + 7 * nk_st : nullptr;          // centres [2nc], ids [nc]
+    int32_t *const rg_ = rec.r ? rec.r + 7 * nk_st + 3 * nc : nullptr;  // group centres, counts
     // ---- 4. truncated integer mean per group (post_process.py:38-41) ------
     for (int g = tid; g < ng; g += kBlock) {
       gsumx[g] = 0;
@@ -526,6 +686,11 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       atomicAdd(&gsumy[g], (int)(ckey[i] & 0xffffu));
       atomicAdd(&gcnt[g], 1);
       o_cgid[i] = g;
+      if (rc_) {
+        rc_[2 * i] = (int)(ckey[i] >> 16);
+        rc_[2 * i + 1] = (int)(ckey[i] & 0xffffu);
+        rc_[2 * nc + i] = g;
+      }
     }
     __syncthreads();
     for (int g = tid; g < ng; g += kBlock) {
@@ -538,9 +703,14 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       if (g < a.max_groups) {
         o_gc[2 * g] = mx;
         o_gc[2 * g + 1] = my;
+        if (rg_) {
+          rg_[2 * g] = mx;
+          rg_[2 * g + 1] = my;
+        }
       }
     }
     __syncthreads();
+    DSTAMP(8);
     // ---- 5. keypoint -> first centre within thr (post_process.py:61-66,173-179);
     //         flags bit2: the north star's variant, the NEAREST centre within thr
     //         (ties to the lower group index)
@@ -555,24 +725,36 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       for (int g = 0; g < ng; ++g) {
         const double dx = rx - (double)gsumx[g];
         const double dy = ry - (double)gsumy[g];
-        const double d = sqrt(dx * dx + dy * dy);
+        const double ss = dx * dx + dy * dy;
+        if (!nearest) {
+          if (ss <= U) {                    // = sqrt(ss) <= T
+            found = g;
+            break;
+          }
+          continue;
+        }
+        const double d = sqrt(ss);
         if (d <= T && (found < 0 || d < best)) {
           found = g;
           best = d;
-          if (!nearest) break;
         }
       }
       o_kgid[i] = found;
       if (found >= 0) atomicAdd(&gcnt[found], 1);
+      if (rec.r) put_kpt(i, found);
     }
     __syncthreads();
-    for (int g = tid; g < min(ng, a.max_groups); g += kBlock) o_gn[g] = gcnt[g];
+    DSTAMP(9);
+    for (int g = tid; g < min(ng, a.max_groups); g += kBlock) {
+      o_gn[g] = gcnt[g];
+      if (rg_) rg_[2 * min(ng, a.max_groups) + g] = gcnt[g];
+    }
     }
   } else {
     // ---- no centre clustering: update_coords_fast (post_process.py:142-153)
     // Greedy over keypoints in order; group ids live in LDS while they fit,
     // else in the (workgroup-coherent) output array.
-    const double T = a.cluster_thr;
+    const double U = a.cluster_sq;
     __syncthreads();  // o_root written above by the whole block
     const bool in_lds = nk_st <= kLdsGid;
     volatile int *kg = in_lds ? (volatile int *)smem : (volatile int *)o_kgid;
@@ -584,8 +766,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
         for (int j = lane; j < i; j += 64) {
           const double dx = rx - (double)o_root[2 * j];
           const double dy = ry - (double)o_root[2 * j + 1];
-          const double d = sqrt(dx * dx + dy * dy);
-          if (d <= T) best = min(best, (int)kg[j]);
+          if (dx * dx + dy * dy <= U) best = min(best, (int)kg[j]);      // = sqrt(.) <= cluster_thr
         }
         best = wave_min(best);
         const int g = (best == INT_MAX) ? ngl++ : best;
@@ -603,6 +784,20 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       if (in_lds) o_kgid[i] = g;
       if (g < a.max_groups) atomicAdd(&o_gn[g], 1);
     }
+    take_record(ng);     // (its barrier also orders the atomics above before the reads below)
+    if (rec.r) {
+      for (int i = tid; i < nk_st; i += kBlock) put_kpt(i, kg[i]);
+      // the centre list sits in the output arrays (kg may have taken its place in LDS);
+      // centre ids are not formed in this mode: the array's words go out as they are,
+      // like decode_pack_kernel's copy
+      for (int i = tid; i < nc; i += kBlock) {
+        rec.r[7 * nk_st + 2 * i] = o_cxy[2 * i];
+        rec.r[7 * nk_st + 2 * i + 1] = o_cxy[2 * i + 1];
+        rec.r[7 * nk_st + 2 * nc + i] = o_cgid[i];
+      }
+      for (int g = tid; g < min(ng, a.max_groups); g += kBlock)
+        rec.r[7 * nk_st + 3 * nc + g] = (int)atomicAdd(&o_gn[g], 0);   // read where it was added
+    }
   }
   if (ng > a.max_groups) overflow |= 4;
   if (tid == 0) {
@@ -615,6 +810,26 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     o_counts[6] = 0;
     o_counts[7] = 0;
   }
+  if constexpr (DECODE) {
+    if (a.packed && tid == 0) {
+      int32_t *hdr = a.packed + (size_t)b * 8;
+      hdr[0] = nk;
+      hdr[1] = nc_found;
+      hdr[2] = ng;
+      hdr[3] = overflow | (rec.fits ? 0 : 8);
+      hdr[4] = rec.off;
+      hdr[5] = rec.words;
+      if (b != 0) hdr[6] = 0;
+      hdr[7] = 0;
+      // the last image to get here knows the total (every image took its words before)
+      if (atomicAdd(a.pack_ctr + 1, 1ull) == (unsigned long long)(a.B - 1)) {
+        const unsigned long long total = atomicExch(a.pack_ctr, 0ull);
+        atomicExch(a.pack_ctr + 1, 0ull);
+        a.packed[6] = (int)(total < 0x7fffffffull ? total : 0x7fffffffull);
+      }
+    }
+  }
+  DSTAMP(10);
 }
 
 // Compacts the capacity-strided per-image arrays into one dense record stream so
@@ -693,6 +908,13 @@ __global__ __launch_bounds__(kBlock) void decode_pack_kernel(
 
 }  // namespace
 
+#ifdef GANET_DECODE_STAMPS
+extern "C" int ganet_debug_decode_stamps(unsigned long long *host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_decode_stamps), 16 * sizeof(unsigned long long)) == hipSuccess
+             ? GANET_OK : GANET_ERR_HIP;
+}
+#endif
+
 extern "C" int ganet_decode_pack(const ganet_decode_params *p,
                                  const ganet_decode_out *out, int32_t *packed,
                                  size_t packed_words, ganet_stream_t stream) {
@@ -739,9 +961,13 @@ int decode_batch_check(const float *heat, const float *offset, const float *erro
   return GANET_OK;
 }
 
+// `packed` != nullptr asks for the record stream as well (ganet_decode_batch_packed): written
+// by the group kernel itself where one workgroup per image does everything, by
+// decode_pack_kernel behind the grid-wide kernels of large by-centre images.
 int decode_batch_launch(const float *heat, const float *offset, const float *error,
                         const ganet_decode_params *p, const ganet_decode_out *out,
-                        unsigned long long *kmask, hipStream_t s) {
+                        unsigned long long *kmask, hipStream_t s, int32_t *packed = nullptr,
+                        size_t packed_words = 0, unsigned long long *pack_ctr = nullptr) {
   const int HW = p->H * p->W;
   const int nwords = (HW + 63) / 64;
 
@@ -771,11 +997,23 @@ int decode_batch_launch(const float *heat, const float *offset, const float *err
   a.root_thr = p->root_thr;
   a.cluster_thr = p->cluster_thr;
   a.by_center_thr = p->by_center_thr;
+  a.cluster_sq = sqrt_le_bound(p->cluster_thr);
+  a.by_center_sq = sqrt_le_bound(p->by_center_thr);
   a.max_kpts = p->max_kpts;
   a.max_centers = p->max_centers;
   a.max_groups = p->max_groups;
   a.flags = p->flags;
   a.out = *out;
+  a.packed = nullptr;
+  a.packed_words = 0;
+  a.pack_ctr = nullptr;
+  a.B = p->B;
+  auto pack_behind = [&]() {
+    hipLaunchKernelGGL(decode_pack_kernel, dim3(p->B), dim3(kBlock), 0, s, *out, p->B,
+                       p->max_kpts, p->max_centers, p->max_groups,
+                       p->by_center_thr >= 0 ? 1 : 0, packed, (long long)packed_words);
+    return ganet_check_launch();
+  };
   if (split) {
     dim3 gg((nwords + kBlock - 1) / kBlock, p->B);
     hipLaunchKernelGGL(decode_gather_kernel, gg, dim3(kBlock), 0, s, a);
@@ -786,7 +1024,13 @@ int decode_batch_launch(const float *heat, const float *offset, const float *err
       dim3 ga((p->max_kpts + kBlock - 1) / kBlock, p->B);
       hipLaunchKernelGGL(decode_assign_kernel, ga, dim3(kBlock), 0, s, a);
     }
-    return ganet_check_launch();
+    if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    return packed ? pack_behind() : GANET_OK;
+  }
+  if (packed) {
+    a.packed = packed;
+    a.packed_words = (long long)(packed_words < (size_t)INT32_MAX ? packed_words : INT32_MAX);
+    a.pack_ctr = pack_ctr;
   }
   hipLaunchKernelGGL(decode_group_kernel<0>, dim3(p->B), dim3(kBlock), 0, s, a);
   return ganet_check_launch();
@@ -838,6 +1082,28 @@ extern "C" int ganet_decode_batch(const float *heat, const float *offset,
                              static_cast<hipStream_t>(stream));
 }
 
+extern "C" size_t ganet_decode_packed_workspace_bytes(const ganet_decode_params *p) {
+  const size_t n = ganet_decode_workspace_bytes(p);
+  return n ? n + 256 : 0;   // + the two counters of the record stream, on a line of their own
+}
+
+extern "C" int ganet_decode_batch_packed(const float *heat, const float *offset,
+                                         const float *error, const ganet_decode_params *p,
+                                         const ganet_decode_out *out, int32_t *packed,
+                                         size_t packed_words, void *workspace,
+                                         size_t workspace_bytes, ganet_stream_t stream) {
+  if (!workspace || !packed) return GANET_ERR_NULL;
+  const int rc = decode_batch_check(heat, offset, error, p, out);
+  if (rc != GANET_OK) return rc;
+  if (packed_words < (size_t)p->B * 8) return GANET_ERR_WORKSPACE;
+  if (workspace_bytes < ganet_decode_packed_workspace_bytes(p)) return GANET_ERR_WORKSPACE;
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  return decode_batch_launch(
+      heat, offset, error, p, out, reinterpret_cast<unsigned long long *>(ws),
+      static_cast<hipStream_t>(stream), packed, packed_words,
+      reinterpret_cast<unsigned long long *>(ws + ganet_decode_workspace_bytes(p)));
+}
+
 extern "C" int ganet_decode_batch_noalloc(const float *heat, const float *offset,
                                           const float *error,
                                           const ganet_decode_params *p,
@@ -871,6 +1137,8 @@ extern "C" int ganet_group_batch(const ganet_decode_params *p,
   a.W = p->W;
   a.cluster_thr = p->cluster_thr;
   a.by_center_thr = p->by_center_thr;
+  a.cluster_sq = sqrt_le_bound(p->cluster_thr);
+  a.by_center_sq = sqrt_le_bound(p->by_center_thr);
   a.max_kpts = p->max_kpts;
   a.max_centers = p->max_centers;
   a.max_groups = p->max_groups;

@@ -83,6 +83,24 @@ class DecodeBuffers(object):
         return v
 
 
+def records_in_image_order(header, records):
+    """(header, records) with the records one after the other in image order, as
+    ganet_decode_pack lays them out.  ganet_decode_batch_packed's one-launch form places a record
+    where its image got to first; the words of every record are the same either way, so this
+    only moves them (and rewrites header[:, 4]).  A stream with records that did not fit
+    (overflow bit 3) is returned as it is."""
+    off, words = header[:, 4].astype(np.int64), header[:, 5].astype(np.int64)
+    if (header[:, 3] & 8).any():
+        return header, records
+    dense = np.cumsum(words) - words
+    if np.array_equal(dense, off):
+        return header, records
+    idx = np.repeat(off - dense, words) + np.arange(int(words.sum()), dtype=np.int64)
+    header = header.copy()
+    header[:, 4] = dense
+    return header, records[idx]
+
+
 class DecodeResult(object):
     """Host copy of a decoded batch: the header [B,8] and the dense record
     stream of ganet_decode_pack.  image(b) slices one image's arrays out."""
@@ -202,16 +220,17 @@ def decode_batch(heat, offset, error, thr=0.1, root_thr=1, cluster_thr=4,
                     (FLAG_LOGITS if logits else 0))
         with torch.cuda.device(heat.device):
             bufs = DecodeBuffers(B, caps[0], caps[1], caps[2], heat.device)
-            ws_bytes = L.ganet_decode_workspace_bytes(ctypes.byref(p))
-            ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=heat.device)
+            # decode, grouping and the record stream in one call (one launch where a
+            # workgroup per image does it all); its counters start at zero
+            ws_bytes = L.ganet_decode_packed_workspace_bytes(ctypes.byref(p))
+            ws = torch.zeros(max(ws_bytes, 256), dtype=torch.uint8, device=heat.device)
             stream = torch.cuda.current_stream(heat.device).cuda_stream
-            rc = L.ganet_decode_batch(heat.data_ptr(), offset.data_ptr(),
-                                      error.data_ptr(), ctypes.byref(p),
-                                      ctypes.byref(bufs.out), ws.data_ptr(),
-                                      ws_bytes, stream)
-            _lib.check(rc, "ganet_decode_batch")
-            bufs.pack(L, p, stream)
-            header, records = bufs.fetch()
+            rc = L.ganet_decode_batch_packed(heat.data_ptr(), offset.data_ptr(),
+                                             error.data_ptr(), ctypes.byref(p),
+                                             ctypes.byref(bufs.out), bufs.packed.data_ptr(),
+                                             bufs.packed_words, ws.data_ptr(), ws_bytes, stream)
+            _lib.check(rc, "ganet_decode_batch_packed")
+            header, records = records_in_image_order(*bufs.fetch())
         counts = header[:, :4]
         over = int(np.bitwise_or.reduce(counts[:, 3])) & 7
         if over == 0:

@@ -17,7 +17,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .decode import DecodeBuffers, DecodeResult, _params
+from .decode import DecodeBuffers, DecodeResult, _params, records_in_image_order
 
 
 class HotPath(object):
@@ -92,8 +92,10 @@ class HotPath(object):
             self.cur = 0
             self.last = None
             self.bufs = self.slots[0]["bufs"]
-            self.dws_bytes = self.L.ganet_decode_workspace_bytes(ctypes.byref(self.dp))
-            self.dws = torch.empty(max(self.dws_bytes, 256), dtype=torch.uint8,
+            # (zero-filled: the counters of ganet_decode_batch_packed start at zero, and every
+            # call leaves them there)
+            self.dws_bytes = self.L.ganet_decode_packed_workspace_bytes(ctypes.byref(self.dp))
+            self.dws = torch.zeros(max(self.dws_bytes, 256), dtype=torch.uint8,
                                    device=self.device)
             self.overlap_copy = overlap_copy
             # side_decode: decode + grouping + pack go to a stream of their own.  They do
@@ -160,23 +162,26 @@ class HotPath(object):
         # the block is free again once its previous copy has finished
         if self.overlap_copy:
             cur_stream.wait_event(slot["copied"])
-        rc = self.L.ganet_decode_batch(
-            heat.data_ptr(), offset.data_ptr(), error.data_ptr(),
-            ctypes.byref(self.dp), ctypes.byref(slot["bufs"].out),
-            self.dws.data_ptr(), self.dws_bytes, cur_stream.cuda_stream)
-        _lib.check(rc, "ganet_decode_batch")
         if copy_to_host and self.pack_to_host:
-            # the pack kernel writes the dense record stream straight into the pinned
-            # host block (it only ever writes `packed`): no copy engine, no extra launch
-            rc = self.L.ganet_decode_pack(
+            # the record stream goes straight into the pinned host block, from the kernel
+            # that groups the keypoints where one workgroup per image does the whole decode
+            # (one launch), else from the pack kernel behind the decode's: no copy engine
+            rc = self.L.ganet_decode_batch_packed(
+                heat.data_ptr(), offset.data_ptr(), error.data_ptr(),
                 ctypes.byref(self.dp), ctypes.byref(slot["bufs"].out),
-                slot["host"].data_ptr(), slot["host"].numel(), cur_stream.cuda_stream)
-            _lib.check(rc, "ganet_decode_pack")
+                slot["host"].data_ptr(), slot["host"].numel(),
+                self.dws.data_ptr(), self.dws_bytes, cur_stream.cuda_stream)
+            _lib.check(rc, "ganet_decode_batch_packed")
             slot["direct"] = True
             slot["ready"].record(cur_stream)
             self.last = slot
             self.cur = (self.cur + 1) % len(self.slots)
             return
+        rc = self.L.ganet_decode_batch(
+            heat.data_ptr(), offset.data_ptr(), error.data_ptr(),
+            ctypes.byref(self.dp), ctypes.byref(slot["bufs"].out),
+            self.dws.data_ptr(), self.dws_bytes, cur_stream.cuda_stream)
+        _lib.check(rc, "ganet_decode_batch")
         slot["direct"] = False
         slot["bufs"].pack(self.L, self.dp, cur_stream.cuda_stream)
         if copy_to_host:
@@ -224,12 +229,17 @@ class HotPath(object):
         self.side_done.record(torch.cuda.current_stream(self.device))
         self._side_busy = True
 
-    def capture(self, x, pts, heat, offset, error):
+    def capture(self, x, pts, heat, offset, error, fork=False):
         """Record one step on these (fixed) input tensors into a HIP graph and return
         it; `graph.replay()` then enqueues the whole step with one host call (at batch 1
         the host launch cost is a quarter of the step).  The step allocates nothing and
         never synchronises, so it captures as it stands; `result()` works after a replay
-        as after `step()`."""
+        as after `step()`.  fork=True: the LFA and the decode do not depend on one another, so
+        they are recorded as two branches of the graph (a second stream forks off the
+        capturing one and joins it again).  Measured SLOWER at batch 1 on MI355X / ROCm 7.2
+        (43.3 against 33.1 us per replay, profiles/r03c_bench_c1_bf16_graph*.json: the two
+        branches run on two hardware queues and the fork and the join cost more than the
+        17 us of overlap they buy), hence off by default."""
         assert not self.overlap_copy and self.side is None, "capture needs the single-stream flow"
         cur = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(device=self.device)
@@ -240,10 +250,20 @@ class HotPath(object):
         cur.synchronize()
         first = self.cur
         graph = torch.cuda.CUDAGraph()
+        branch = torch.cuda.Stream(device=self.device) if fork else None
         with torch.cuda.graph(graph):
             self.cur = first                # the graph always writes this result block
-            self.step(x, pts, heat, offset, error)
+            if branch is None:
+                self.step(x, pts, heat, offset, error)
+            else:
+                main = torch.cuda.current_stream(self.device)
+                branch.wait_stream(main)    # fork
+                self.lfa(x, pts)
+                with torch.cuda.stream(branch):
+                    self.decode(heat, offset, error)
+                main.wait_stream(branch)    # join
         self.cur = (first + 1) % len(self.slots)
+        self._graph_branch = branch         # keep the stream alive as long as the graph may
         return graph
 
     def result(self, slot=None):
@@ -262,8 +282,11 @@ class HotPath(object):
             slot["ready"].synchronize()
         host, total = self._host_stream(slot)
         hw = slot["bufs"].header_words
-        header = host[:hw].reshape(self.B, _lib.DECODE_COUNT_STRIDE)
-        return DecodeResult(header.copy(), host[hw:total].copy(), self.params, grouped=True)
+        header = host[:hw].reshape(self.B, _lib.DECODE_COUNT_STRIDE).copy()
+        records = host[hw:total].copy()
+        if slot.get("direct"):    # (one-launch decode: records sit in arrival order)
+            header, records = records_in_image_order(header, records)
+        return DecodeResult(header, records, self.params, grouped=True)
 
     def _host_stream(self, slot):
         bufs, host = slot["bufs"], slot["host"].numpy()

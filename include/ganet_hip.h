@@ -372,6 +372,25 @@ int ganet_group_batch(const ganet_decode_params *p, const ganet_decode_out *out,
 int ganet_decode_pack(const ganet_decode_params *p, const ganet_decode_out *out,
                       int32_t *packed, size_t packed_words, ganet_stream_t stream);
 
+/* ganet_decode_batch and ganet_decode_pack as ONE call: `out` is filled as by
+ * ganet_decode_batch and `packed` (device memory or host memory the device can write, e.g. a
+ * pinned block) receives the record stream of ganet_decode_pack - header and record layout
+ * as above, every record's words identical.  Replaces ktdet_decode_fast's three blocking
+ * device-to-host copies (ganet_head.py:217,232-233) with stores that leave the kernel which
+ * found the keypoints.  Where one workgroup per image does the whole decode (every image of at
+ * most 8192 pixels, and the no-centre mode at any size) this is a single launch and the
+ * records are laid out in the order the images finished sizing them, NOT in image order:
+ * readers go by header[b][4..5] (ganet_lanes_from_packed does).  Larger by-centre images run
+ * ganet_decode_batch's kernels followed by the pack kernel (image order).
+ * Workspace: ganet_decode_packed_workspace_bytes(p) bytes, 8-byte aligned, ZERO-FILLED ONCE
+ * before its first use (hipMemset): its last 256 bytes hold two counters that every call
+ * leaves at zero again.  Calls that share a workspace must be ordered on one stream. */
+size_t ganet_decode_packed_workspace_bytes(const ganet_decode_params *p);
+int ganet_decode_batch_packed(const float *heat, const float *offset, const float *error,
+                              const ganet_decode_params *p, const ganet_decode_out *out,
+                              int32_t *packed, size_t packed_words, void *workspace,
+                              size_t workspace_bytes, ganet_stream_t stream);
+
 /* ---- after grouping: records -> the reference's result formats (host code) -----------
  * The reference runs these per image in Python (one interpreter step per point); here one
  * call formats a whole batch from the record stream of ganet_decode_pack on `threads` host

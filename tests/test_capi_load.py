@@ -206,6 +206,13 @@ def test_decode_validation_without_gpu():
     rc = L.ganet_decode_batch(fake, fake, fake, ctypes.byref(p), ctypes.byref(out),
                               fake, 8, None)
     assert rc == _lib.GANET_ERR_WORKSPACE
+    # decode + record stream in one call: the same checks, plus the stream and the counters
+    need = L.ganet_decode_packed_workspace_bytes(ctypes.byref(p))
+    assert need == L.ganet_decode_workspace_bytes(ctypes.byref(p)) + 256
+    args = (fake, fake, fake, ctypes.byref(p), ctypes.byref(out))
+    assert L.ganet_decode_batch_packed(*args, None, 1 << 20, fake, need, None) == _lib.GANET_ERR_NULL
+    assert L.ganet_decode_batch_packed(*args, fake, 8 * 4 - 1, fake, need, None) == _lib.GANET_ERR_WORKSPACE
+    assert L.ganet_decode_batch_packed(*args, fake, 1 << 20, fake, need - 1, None) == _lib.GANET_ERR_WORKSPACE
 
 
 def test_ops_refuse_cpu_tensors():

@@ -188,3 +188,35 @@ def test_logits_prologue_matches_torch_sigmoid_clamp(shape, B):
         check_image_against(g, c, al, rt, gid, means, ng)
         total += len(kxy)
     assert total > 50 * B
+
+
+@pytest.mark.parametrize("H,W", [(40, 100), (7, 9), (1, 5), (5, 1), (3, 16), (9, 17), (64, 128), (2, 33)])
+@pytest.mark.parametrize("thr", [0.3, -0.5, 0.0])
+def test_nms_special_values_match_oracle(H, W, thr):
+    """The 1x3 NMS of the one-workgroup decode (16 pixels per thread, two comparisons per
+    pixel) on the values where ATen's pool is particular: NaN, +-inf, +-0, plateaus, row ends,
+    rows shorter than a thread's run, a threshold below zero (h * 0 = 0 passes it).  The oracle's
+    NMS is pinned to torch.max_pool2d (tests/test_decode_variants.py)."""
+    rng = np.random.default_rng(H * 1000 + W)
+    B = 3
+    heat = np.round(rng.uniform(-0.2, 1, (B, 1, H, W)) * 8).astype(np.float32) / 8
+    flat = heat.reshape(B, -1)
+    n = flat.shape[1]
+    for b in range(B):
+        for val in (np.nan, np.inf, -np.inf, -0.0, 0.0):
+            flat[b, rng.integers(0, n, max(1, n // 40))] = val
+        flat[b, 0] = (np.nan, np.inf, 0.5)[b]                  # first pixel of the image
+        flat[b, n - 1] = (0.5, np.nan, -np.inf)[b]              # last pixel
+        if H > 1:
+            flat[b, W - 1] = np.nan                             # a row end beside a row start
+            flat[b, W] = 1.0
+    off = rng.normal(0, 3, (B, 2, H, W)).astype(np.float32)
+    err = rng.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
+    res = D.decode_batch(cuda(heat), cuda(off), cuda(err), thr=thr, root_thr=-5.0, cluster_thr=4,
+                         cluster_by_center_thr=4, group=False, max_kpts=H * W, max_centers=min(H * W, 2048))
+    for b in range(B):
+        c, kxy, al, rt = O.decode(heat[b, 0], off[b], err[b], thr, -5.0)
+        img = res.image(b)
+        assert np.array_equal(img["kpt_xy"], kxy)
+        assert img["align"].tobytes() == al.tobytes() and img["root"].tobytes() == rt.tobytes()
+        assert np.array_equal(img["centers"], c)

@@ -5,9 +5,10 @@ TAG=$1; shift
 OUT=gpurun_out/lines_$TAG
 mkdir -p $OUT
 for dt in fp32 bf16; do
-  for mode in eager graph; do
+  for mode in eager graph graphfork; do   # graph: one chain; graphfork: LFA and decode as two branches
     extra="--no-backward --steps 2000 --warmup 200 --spinup 2000 --single-stream"
     [ $mode = graph ] && extra="$extra --graph"
+    [ $mode = graphfork ] && extra="$extra --graph --graph-fork"
     f=$OUT/bench_c1_${dt}_${mode}.json
     timeout -k 10 300 python bench.py --workload c1 --dtype $dt $extra "$@" > $f 2> ${f%.json}.err || { echo "FAILED c1 $dt $mode"; tail -5 ${f%.json}.err; exit 1; }
     python - <<PY
