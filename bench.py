@@ -600,9 +600,9 @@ def main():
 
     if rank == 0:
         nbytes, flops = lfa_algorithmic(B, Cin, 64, H, W, K, dtype)
-        # float32 tensors on algorithm 2 are contracted as three bf16 MFMA passes
+        # float32 tensors on algorithms 1 and 2 are contracted as three bf16 MFMA passes
         # (hi*hi + hi*lo + lo*hi): price the matrix work as 3x the FLOPs at the bf16 peak
-        split = dtype == "fp32" and hp.lfa_algorithm == 2 and args.fp32_mode == "auto"
+        split = dtype == "fp32" and hp.lfa_algorithm in (1, 2) and args.fp32_mode == "auto"
         arith = dtype
         if split:
             flops *= 3.0

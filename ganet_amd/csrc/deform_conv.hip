@@ -125,24 +125,37 @@ __device__ __forceinline__ void wave_lds_sync() {
 // pipelined one step (16 buffer loads per lane-group) ahead of the blend, across
 // chunk and tap boundaries, so the memory pipe stays busy while a wave blends,
 // writes LDS and issues its MFMAs.
-template <typename TA, typename TO, int KCB, int NW>
+//
+// SPLIT (float32 tensors, ganet_dcn_params.mfma_bf16 == 0): the gather and the blend stay
+// float32, but the blended tile goes to LDS as two bf16 planes per row - hi = bf16(v),
+// lo = bf16(v - hi) - the weights arrive pre-split the same way (pack_weight_split_kernel),
+// and the contraction runs on the bf16 matrix cores as hi*hi + hi*lo + lo*hi with float32
+// accumulation (products of two bf16 are exact in float32; what is dropped is <= 3 * 2^-18 of
+// a term): 12 MFMA 32x32x16 per 32-channel chunk instead of 32 float32 MFMA 32x32x2 at 1/16 of
+// the rate.  Same LDS bytes as the float32 tiles.
+template <typename TA, typename TO, int KCB, int NW, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
+  static_assert(!SPLIT || sizeof(TA) == 4, "the split form contracts float32 tensors");
+  using TM = typename std::conditional<SPLIT, bf16_t, TA>::type;   // LDS tile / MFMA operand element
   constexpr int ES = sizeof(TA);
-  constexpr int EPL = 16 / ES;                          // elements per 16-B piece
+  constexpr int MS = sizeof(TM);
+  constexpr int EPL = 16 / ES;                          // gathered elements per 16-B piece
+  constexpr int EPM = 16 / MS;                          // tile elements per 16-B piece
   constexpr int KC = (KCB * ES > 128) ? 128 / ES : KCB; // gather chunk (elements)
   constexpr int NSUB = KCB / KC;                        // gather chunks per weight chunk
   constexpr int LPP = KC / EPL;                         // lanes per pixel chunk
   constexpr int PPL = 64 / LPP;                         // pixels per load instruction
   constexpr int NPASS = 32 / PPL;                       // load passes per gather chunk
   constexpr int GROUP = NPASS;                          // one pipeline step = one chunk
-  constexpr int LDA = KC + EPL;                         // +16 B: conflict-free b128 reads
-  constexpr int LDB = KCB + EPL;
+  constexpr int PLANES = SPLIT ? 2 : 1;                 // hi | lo side by side in a tile row
+  constexpr int LDA = PLANES * KC + EPM;                // +16 B: conflict-free b128 reads
+  constexpr int LDB = PLANES * KCB + EPM;
   constexpr int TMW = 32;                               // pixels per wavefront
   constexpr int TMB = NW * TMW;                         // pixels per workgroup
-  typedef typename Mma<TA>::frag frag_t;
+  typedef typename Mma<TM>::frag frag_t;
 
-  constexpr int B_BYTES = TN * LDB * ES;                // one weight buffer
-  constexpr int A_BYTES = TMW * LDA * ES;               // one wave's A tile (x2: double buffer)
+  constexpr int B_BYTES = TN * LDB * MS;                // one weight buffer
+  constexpr int A_BYTES = TMW * LDA * MS;               // one wave's A tile (x2: double buffer)
   constexpr int C_BYTES = 32 * (TMW + 1) * 4;           // NCHW transpose of one 32x32 block
   constexpr int A0_BYTES = A_BYTES > C_BYTES ? A_BYTES : C_BYTES;  // A buffer 0 / transpose
   __shared__ __attribute__((aligned(16))) unsigned char s_b[2 * B_BYTES];
@@ -170,9 +183,10 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
   const int n0 = blockIdx.y * TN;
   const int HWo = a.Ho * a.Wo;
   const int T = a.kH * a.kW;
-  const TA *wp = static_cast<const TA *>(a.wp);
-  TA *A0 = reinterpret_cast<TA *>(s_a0 + wid * A0_BYTES);   // chunks 0, 2, 4, ...
-  TA *A1 = reinterpret_cast<TA *>(s_a1 + wid * A_BYTES);    // chunks 1, 3, 5, ...
+  const TM *wp = static_cast<const TM *>(a.wp);
+  const size_t w_plane = (size_t)T * a.CoutP * a.Cp;          // SPLIT: the lo plane follows the hi plane
+  TM *A0 = reinterpret_cast<TM *>(s_a0 + wid * A0_BYTES);   // chunks 0, 2, 4, ...
+  TM *A1 = reinterpret_cast<TM *>(s_a1 + wid * A_BYTES);    // chunks 1, 3, 5, ...
 
   // Buffer window of this tile: starts at the first image the tile touches and is
   // clamped below 2 GiB, so 32-bit offsets address it and OOB_OFFSET is outside.
@@ -255,7 +269,11 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
   };
 
   // weight chunk: global -> registers (early) -> LDS buffer (late)
-  constexpr int BPIECES = TN * (KCB / EPL);
+  // (SPLIT: a row's chunk is KCB/8 pieces of the hi plane, then KCB/8 of the lo plane -
+  // as many 16-B pieces as the float32 chunk has)
+  constexpr int PPR = PLANES * KCB / EPM;               // 16-B pieces per row and chunk
+  constexpr int PPP = KCB / EPM;                        // ... per plane
+  constexpr int BPIECES = TN * PPR;
   constexpr int BPT = (BPIECES + NW * 64 - 1) / (NW * 64);
   u32x4 breg[BPT];
   auto load_b = [&](int t, int cbase) {
@@ -263,19 +281,22 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
     for (int j = 0; j < BPT; ++j) {
       const int q = tid + j * NW * 64;
       if (BPIECES % (NW * 64) == 0 || q < BPIECES) {
-        const int row = q / (KCB / EPL), pc = q - row * (KCB / EPL);
-        breg[j] = ldg128(wp + ((size_t)(t * a.CoutP + n0 + row) * a.Cp + cbase + pc * EPL));
+        const int row = q / PPR, pc = q - row * PPR;
+        const int plane = pc / PPP, pw = pc - plane * PPP;
+        breg[j] = ldg128(wp + plane * w_plane +
+                         ((size_t)(t * a.CoutP + n0 + row) * a.Cp + cbase + pw * EPM));
       }
     }
   };
   auto store_b = [&](int buf) {
-    TA *Bs = reinterpret_cast<TA *>(s_b + buf * B_BYTES);
+    TM *Bs = reinterpret_cast<TM *>(s_b + buf * B_BYTES);
 #pragma unroll
     for (int j = 0; j < BPT; ++j) {
       const int q = tid + j * NW * 64;
       if (BPIECES % (NW * 64) == 0 || q < BPIECES) {
-        const int row = q / (KCB / EPL), pc = q - row * (KCB / EPL);
-        *reinterpret_cast<u32x4 *>(Bs + row * LDB + pc * EPL) = breg[j];
+        const int row = q / PPR, pc = q - row * PPR;
+        const int plane = pc / PPP, pw = pc - plane * PPP;
+        *reinterpret_cast<u32x4 *>(Bs + row * LDB + plane * KCB + pw * EPM) = breg[j];
       }
     }
   };
@@ -299,13 +320,38 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
       v[u][3] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.w + lane_off, 0, 0);
     }
   };
-  auto blend = [&](u32x4 (&v)[GROUP][4], int slot, TA *Adst) {
+  auto blend = [&](u32x4 (&v)[GROUP][4], int slot, TM *Adst) {
 #pragma unroll
     for (int u = 0; u < GROUP; ++u) {
       const int r = u * PPL + pq;
       const float4 w = *reinterpret_cast<const float4 *>(s_w[wid][slot][r]);
       const u32x4 o = Blend<TA>::run(v[u], w);
-      *reinterpret_cast<u32x4 *>(Adst + r * LDA + lp * EPL) = o;
+      if constexpr (SPLIT) {
+        // four blended floats -> 4 hi + 4 lo bf16, 8 bytes each
+        uint2 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float x0 = __uint_as_float(o[2 * k]), x1 = __uint_as_float(o[2 * k + 1]);
+          // hi = x cut to its upper 16 bits (exact), lo = x - hi rounded to nearest even on
+          // the 16 bits it drops: integer operations only.  (v_cvt_pk_bf16_f32 is NOT used here:
+          // with this instruction in the blend, pixels held by lanes 48-63 came out wrong now and
+          // then whenever two wavefronts shared a SIMD - 12 x 34x106 x Cin 64 and every other
+          // shape at occupancy 2, never at occupancy 1; waits, no-ops and full barriers around it
+          // changed nothing, these integer forms made it go away.  Recorded in DESIGN 3.1 (1s).)
+          const unsigned int u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+          const unsigned int h0 = u0 & 0xffff0000u, h1 = u1 & 0xffff0000u;
+          const unsigned int l0 = __float_as_uint(x0 - __uint_as_float(h0));
+          const unsigned int l1 = __float_as_uint(x1 - __uint_as_float(h1));
+          const unsigned int r0 = l0 + 0x7fffu + ((l0 >> 16) & 1u);
+          const unsigned int r1 = l1 + 0x7fffu + ((l1 >> 16) & 1u);
+          (k == 0 ? hi.x : hi.y) = (h0 >> 16) | h1;
+          (k == 0 ? lo.x : lo.y) = (r0 >> 16) | (r1 & 0xffff0000u);
+        }
+        *reinterpret_cast<uint2 *>(Adst + r * LDA + lp * EPL) = hi;
+        *reinterpret_cast<uint2 *>(Adst + r * LDA + KC + lp * EPL) = lo;
+      } else {
+        *reinterpret_cast<u32x4 *>(Adst + r * LDA + lp * EPL) = o;
+      }
     }
   };
 
@@ -352,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
   // scheduler can interleave them; everything conditional (barrier, weight
   // staging, coordinate tables) happens before or after that block.
   auto step = [&](int k, u32x4 (&vcur)[GROUP][4], u32x4 (&vnxt)[GROUP][4],
-                  const TA *Acur, TA *Anxt, auto do_issue, auto do_blend) {
+                  const TM *Acur, TM *Anxt, auto do_issue, auto do_blend) {
     const int sub = k % NSUB;
     const int nbi = k / NSUB;           // weight chunk index
     if (sub == 0) {
@@ -381,10 +427,28 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
     if (decltype(do_issue)::value) issue(vcur, islot, icabs);
     {
       const int i = lane & 31, h = lane >> 5;
-      const TA *Bs = reinterpret_cast<const TA *>(s_b + (nbi & 1) * B_BYTES);
-      const TA *arow = Acur + i * LDA + h * EPL;
-      const TA *brow0 = Bs + i * LDB + sub * KC + h * EPL;
-      const TA *brow1 = brow0 + 32 * LDB;
+      const TM *Bs = reinterpret_cast<const TM *>(s_b + (nbi & 1) * B_BYTES);
+      const TM *arow = Acur + i * LDA + h * EPM;
+      const TM *brow0 = Bs + i * LDB + sub * KC + h * EPM;
+      const TM *brow1 = brow0 + 32 * LDB;
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int q = 0; q < KC / (2 * EPM); ++q) {
+          const frag_t ah = *reinterpret_cast<const frag_t *>(arow + q * 2 * EPM);
+          const frag_t al = *reinterpret_cast<const frag_t *>(arow + KC + q * 2 * EPM);
+          const frag_t bh0 = *reinterpret_cast<const frag_t *>(brow0 + q * 2 * EPM);
+          const frag_t bl0 = *reinterpret_cast<const frag_t *>(brow0 + KCB + q * 2 * EPM);
+          const frag_t bh1 = *reinterpret_cast<const frag_t *>(brow1 + q * 2 * EPM);
+          const frag_t bl1 = *reinterpret_cast<const frag_t *>(brow1 + KCB + q * 2 * EPM);
+          // small terms first, as the float32 sum would want them
+          Mma<TM>::mma(al, bh0, acc0);
+          Mma<TM>::mma(al, bh1, acc1);
+          Mma<TM>::mma(ah, bl0, acc0);
+          Mma<TM>::mma(ah, bl1, acc1);
+          Mma<TM>::mma(ah, bh0, acc0);
+          Mma<TM>::mma(ah, bh1, acc1);
+        }
+      } else
 #pragma unroll
       for (int q = 0; q < KC / (2 * EPL); ++q) {
         const frag_t fa = *reinterpret_cast<const frag_t *>(arow + q * 2 * EPL);
@@ -405,15 +469,15 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
     // address), one LDS and (every other slot) one buffer-load instruction, so the
     // matrix pipe runs while this wave's vector and memory work issues.
     {
-      constexpr int NMFMA = (KC / (2 * EPL)) * 2 * (ES == 4 ? 4 : 1);
-      constexpr int VPER = ES == 4 ? 2 : 10;
+      constexpr int NMFMA = SPLIT ? (KC / (2 * EPM)) * 6 : (KC / (2 * EPL)) * 2 * (ES == 4 ? 4 : 1);
+      constexpr int VPER = SPLIT ? 8 : (ES == 4 ? 2 : 10);
 #pragma unroll
       for (int i = 0; i < NMFMA; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);   // VALU
-        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);      // DS
-        if ((i & 1) == 0 || ES != 4)
-          __builtin_amdgcn_sched_group_barrier(0x020, ES == 4 ? 1 : 2, 0);  // VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x080, SPLIT ? 3 : 1, 0);      // DS
+        if ((i & 1) == 0 || ES != 4 || SPLIT)
+          __builtin_amdgcn_sched_group_barrier(0x020, (ES == 4 && !SPLIT) ? 1 : 2, 0);  // VMEM read
       }
     }
     // ---------------------------------------------------------------------------
@@ -603,6 +667,7 @@ struct Plan {
   bool copy_x;   // a channel-last (and/or converted, padded) copy of x is made
   bool cts;      // contract-then-sample path (deform_conv_cts.hip)
   bool split;    // ... with float32 tensors contracted as three bf16 passes
+  bool fsplit;   // the fused kernel with float32 tensors contracted as three bf16 passes
   bool stream;   // ... as one persistent producer/consumer launch (deform_conv_stream.hip)
   bool ring;     // ... as one launch with Y kept in L2, tap-major (deform_conv_ring.hip)
   bool keep_y;   // the whole batch's per-tap products stay in the workspace (GANET_DCN_ALGO_KEEP_Y)
@@ -690,6 +755,7 @@ int make_plan(const ganet_dcn_params *p_in, Plan *pl) {
   if (p->algo < 0 || p->algo > 4) return GANET_ERR_BAD_SHAPE;
   if (p->algo == 2 && !pl->cts) return GANET_ERR_UNSUPPORTED;
   pl->split = pl->cts && pl->ta == GANET_F32 && cts_split(p, pl->Cp);
+  pl->fsplit = !pl->cts && pl->ta == GANET_F32 && p->mfma_bf16 == 0;
   pl->stream = pl->cts && p->algo == 3 &&
                stream_applicable(p, pl->ta, pl->Cp, pl->CoutP, pl->Ho, pl->Wo);
   if (p->algo == 3 && !pl->stream) return GANET_ERR_UNSUPPORTED;
@@ -742,7 +808,7 @@ void launch_pack_weight(const ganet_dcn_params *p, const Plan &pl, const void *w
                      p->Cin, pl.T, pl.CoutP, pl.Cp, p->groups);
 }
 
-template <typename TA, typename TO, int KCB>
+template <typename TA, typename TO, int KCB, bool SPLIT = false>
 void launch_nw(const Plan &pl, const DcnArgs &a, hipStream_t s) {
   // 8 waves (256 pixels) per workgroup when that still gives every CU work;
   // smaller workgroups for small batches so the grid covers the chip.
@@ -750,25 +816,25 @@ void launch_nw(const Plan &pl, const DcnArgs &a, hipStream_t s) {
   const unsigned ny = (unsigned)(pl.CoutP / TN);
   if (waves >= 8 * 256) {
     dim3 grid((unsigned)((a.P + 255) / 256), ny);
-    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 8>), grid, dim3(512), 0, s, a);
+    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 8, SPLIT>), grid, dim3(512), 0, s, a);
   } else if (waves >= 4 * 128) {
     dim3 grid((unsigned)((a.P + 127) / 128), ny);
-    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 4>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 4, SPLIT>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid((unsigned)((a.P + 63) / 64), ny);
-    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 2>), grid, dim3(128), 0, s, a);
+    hipLaunchKernelGGL((dcn_fused_kernel<TA, TO, KCB, 2, SPLIT>), grid, dim3(128), 0, s, a);
   }
 }
 
-template <typename TA, typename TO>
+template <typename TA, typename TO, bool SPLIT = false>
 void launch_main(const Plan &pl, const DcnArgs &a, hipStream_t s) {
   constexpr int KC_BIG = sizeof(TA) == 4 ? 128 : 256;
   if (pl.kc == KC_BIG)
-    launch_nw<TA, TO, KC_BIG>(pl, a, s);
+    launch_nw<TA, TO, KC_BIG, SPLIT>(pl, a, s);
   else if (pl.kc == KC_BIG / 2)
-    launch_nw<TA, TO, KC_BIG / 2>(pl, a, s);
+    launch_nw<TA, TO, KC_BIG / 2, SPLIT>(pl, a, s);
   else
-    launch_nw<TA, TO, KC_BIG / 4>(pl, a, s);
+    launch_nw<TA, TO, KC_BIG / 4, SPLIT>(pl, a, s);
 }
 
 }  // namespace
@@ -816,7 +882,7 @@ extern "C" size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *
 namespace {
 int pack_weight_dispatch(const ganet_dcn_params *p, const Plan &pl,
                          const void *weight, void *wp, hipStream_t s) {
-  if (pl.split) {
+  if (pl.split || pl.fsplit) {
     const long long total = (long long)pl.T * pl.CoutP * pl.Cp;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weight_split_kernel, dim3(blocks), dim3(256), 0, s,
@@ -927,7 +993,9 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
   a.ablate = p->debug;
   a.P = (long long)p->B * pl.Ho * pl.Wo;
 
-  if (pl.ta == GANET_F32)
+  if (pl.ta == GANET_F32 && pl.fsplit)
+    launch_main<float, float, true>(pl, a, s);
+  else if (pl.ta == GANET_F32)
     launch_main<float, float>(pl, a, s);
   else if (pl.ta == GANET_BF16 && p->dtype == GANET_F32)
     launch_main<bf16_t, float>(pl, a, s);
