@@ -86,12 +86,12 @@ typedef struct {
   int32_t out_layout;       /* ganet_layout of out */
   int32_t mfma_bf16;        /* dtype == GANET_F32 only, how float32 tensors are
                                contracted:
-                               0 = float32-class accuracy (default): the exact
-                                   float32 MFMA, or - where algorithm 2 applies -
-                                   three bf16 MFMA passes over hi/lo splits of
-                                   both operands with float32 accumulation
-                                   (<= 3*2^-18 relative per product, ~4e-6 of the
-                                   output scale; non-finite inputs give NaN);
+                               0 = float32-class accuracy (default): three bf16
+                                   MFMA passes over hi/lo splits of both operands
+                                   with float32 accumulation (algorithm 2 splits x,
+                                   algorithm 1 its blended tile; <= 2^-15 relative
+                                   per product, 4e-6..8e-6 of the output scale;
+                                   non-finite inputs give NaN);
                                1 = round operands to bf16, one bf16 MFMA pass
                                    (~1e-2 of the output scale);
                                2 = exact float32 MFMA only */
