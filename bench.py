@@ -489,6 +489,8 @@ def main():
             gather_group = dist.new_group(backend="gloo") if backend != "gloo" else None
         gather_q = queue.Queue()
 
+    gather_buf = bytearray(16 << 20) if rank == 0 else None
+
     def gather_loop():
         from ganet_amd import sharding
         try:
@@ -497,14 +499,20 @@ def main():
                 if item is None:
                     return
                 if isinstance(gather_group, sharding.NodeGather):
-                    res = gather_group.gather(item[0], item[1])
+                    # every rank sends its lane count beside its block; rank 0 fills one
+                    # buffer that it keeps from step to step
+                    res = gather_group.gather(item[0], item[1], tag=item[2], into=gather_buf)
+                    lanes = sum(gather_group.last_tags)
                 else:
-                    res = sharding.gather_text_blocks(item[0], item[1], dst=0, group=gather_group)
+                    res = sharding.gather_text_blocks(item[0], item[1].tolist(), dst=0, group=gather_group)
+                    lanes = res[0].count(b"\n") if res is not None else 0   # one line per lane
                 if res is not None:
                     gathered["steps"] += 1
                     gathered["images"] += len(res[1])
                     gathered["bytes"] += len(res[0])
-                    gathered["lanes"] += res[0].count(b"\n")   # one line of text per lane
+                    gathered["lanes"] += lanes
+                    if gathered["steps"] == 1 and isinstance(gather_group, sharding.NodeGather):
+                        gathered["first_step_lanes_by_rank"] = list(gather_group.last_tags)
         except Exception as exc:  # noqa: BLE001
             gathered["error"] = repr(exc)
 
@@ -520,7 +528,8 @@ def main():
             # (image b's text is buf[start[b] : start[b] + length[b]]; packed back to back here)
             mv = memoryview(buf)
             text = b"".join([mv[a:a + n] for a, n in zip(start.tolist(), length.tolist())])
-            return int(bl.n_lanes().sum()), len(text), (text, length.tolist())
+            nl = int(bl.n_lanes().sum())
+            return nl, len(text), (text, np.asarray(length, np.int32), nl)
         return int(bl.n_lanes().sum()), int(length.sum()), None
 
     if graph is not None or not wl["decode"]:
@@ -735,6 +744,7 @@ def main():
                                  "bytes_per_step": gathered["bytes"] / max(1, gathered["steps"]),
                                  "images_per_step": gathered["images"] / max(1, gathered["steps"]),
                                  "lanes_per_step": gathered["lanes"] / max(1, gathered["steps"]),
+                                 "first_step_lanes_by_rank": gathered.get("first_step_lanes_by_rank"),
                                  "rank0_images_per_step": B,
                                  "rank0_lanes_per_step": consumed[0] / max(1, args.steps)}
         if world == 1 and not args.no_cpu_baseline:

@@ -138,7 +138,7 @@ int stream_forward(const void *xh, const float *offset, const float *mask, const
                    int CoutP, void *ws, hipStream_t s);
 
 // the same algorithm with Y kept in the forming XCD's L2 (csrc/deform_conv_ring.hip): teams of
-// workgroups on one XCD form Y tap by tap into a two-plane ring and sample it in the same launch
+// workgroups on one XCD form Y tap by tap into a three-plane ring and sample it in the same launch
 bool ring_applicable(const ganet_dcn_params *p, int ta, int Cp, int CoutP, int Ho, int Wo);
 size_t ring_workspace_bytes(const ganet_dcn_params *p);
 int ring_forward(const void *xh, const float *offset, const float *mask, const void *wq,

@@ -103,7 +103,7 @@ class NodeGather(object):
     has mapped it, so nothing outlives the processes) and a Unix-domain stream socket to rank 0
     (abstract address derived from `key`; every rank passes the same key, e.g. the rendezvous
     port).  `gather(text, lengths)` is called once per step by every rank, in the same order:
-    a rank copies its block into its next free slot and writes a 24-byte header to the socket;
+    a rank copies its block into its next free slot and writes a 32-byte header to the socket;
     rank 0 reads the headers in rank order, copies each block from the ring into its place in
     one buffer and returns a one-byte credit.  So a block is copied twice (once by its owner,
     once by rank 0) and the socket carries only headers and credits; its system calls also order
@@ -113,7 +113,7 @@ class NodeGather(object):
     others None.  No
     GPU, no stream and no process group is involved."""
 
-    HEAD = struct.Struct("<qqq")          # bytes of text, images, 1 = in the ring / 0 = follows inline
+    HEAD = struct.Struct("<qqqq")         # bytes of text, images, 1 = in the ring / 0 = follows inline, tag
 
     def __init__(self, rank, world, key, timeout=60.0, block_bytes=2 << 20, slots=8):
         import mmap
@@ -121,6 +121,7 @@ class NodeGather(object):
         self.cap, self.slots = int(block_bytes), int(slots)
         self.peers, self.rings = [], []
         self.sent = self.credit = 0
+        self.last_tags = []
         if world == 1:
             return
         addr = "\0ganet_gather_%s_%d" % (key, os.getuid())
@@ -191,18 +192,25 @@ class NodeGather(object):
         cls._read_into(conn, memoryview(buf))
         return bytes(buf)
 
-    def gather(self, text, lengths):
+    def gather(self, text, lengths, tag=0, into=None):
+        """tag: one integer that travels with the block (the bench sends its lane count, so
+        that rank 0 need not scan the text); rank 0 finds every rank's in `last_tags`.
+        into: a bytearray that rank 0 fills instead of allocating one per step (used when it
+        is large enough; the returned text is then a memoryview of its first bytes and is valid
+        until the next call with the same buffer)."""
         import numpy as np
-        lengths = np.asarray([int(n) for n in lengths], np.int32)
-        if int(lengths.sum()) != len(text):
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32).reshape(-1)
+        if int(lengths.sum(dtype=np.int64)) != len(text):
             raise ValueError("lengths do not add up to the text")
         if self.world == 1:
+            self.last_tags = [int(tag)]
             return bytes(text), lengths.tolist()
         if self.rank != 0:
             so, ring = self.peers[0], self.rings[0]
             need = lengths.nbytes + len(text)
             if need > self.cap:
-                so.sendall(self.HEAD.pack(len(text), len(lengths), 0) + lengths.tobytes() + bytes(text))
+                so.sendall(self.HEAD.pack(len(text), len(lengths), 0, int(tag)) + lengths.tobytes()
+                           + bytes(text))
                 return None
             while self.sent - self.credit >= self.slots:  # rank 0 is `slots` blocks behind: wait
                 got = so.recv(64)                         # one byte per slot that it has freed
@@ -213,21 +221,22 @@ class NodeGather(object):
             ring[at:at + lengths.nbytes] = lengths.tobytes()
             np.frombuffer(ring, np.uint8, len(text), at + lengths.nbytes)[:] = np.frombuffer(text, np.uint8)
             self.sent += 1
-            so.sendall(self.HEAD.pack(len(text), len(lengths), 1))
+            so.sendall(self.HEAD.pack(len(text), len(lengths), 1, int(tag)))
             return None
         heads = []
         for conn in self.peers:
-            nbytes, nimg, in_ring = self.HEAD.unpack(self._read(conn, self.HEAD.size))
+            nbytes, nimg, in_ring, peer_tag = self.HEAD.unpack(self._read(conn, self.HEAD.size))
             if nbytes < 0 or nimg < 0:
                 raise ConnectionError("bad gather header")
-            heads.append((nbytes, nimg, in_ring))
+            heads.append((nbytes, nimg, in_ring, peer_tag))
             if not in_ring:                               # oversized block: it follows in the socket
                 heads[-1] += (self._read(conn, 4 * nimg), self._read(conn, nbytes))
         # numpy does the large copies: it lets go of the interpreter lock meanwhile, and the thread
         # that launches the GPU work of this rank runs on
-        out = bytearray(len(text) + sum(h[0] for h in heads))
+        total = len(text) + sum(h[0] for h in heads)
+        out = into if into is not None and len(into) >= total else bytearray(total)
         dst = np.frombuffer(out, np.uint8)
-        all_lengths = lengths.tolist()
+        parts = [lengths]
         dst[:len(text)] = np.frombuffer(text, np.uint8)
         at = len(text)
         for i, (conn, h) in enumerate(zip(self.peers, heads)):
@@ -236,7 +245,7 @@ class NodeGather(object):
                 ring, cap, slots = self.rings[i]
                 src = (self.taken[i] % slots) * cap
                 self.taken[i] += 1
-                all_lengths.extend(np.frombuffer(ring, np.int32, nimg, src).tolist())
+                parts.append(np.frombuffer(ring, np.int32, nimg, src).copy())
                 dst[at:at + nbytes] = np.frombuffer(ring, np.uint8, nbytes, src + 4 * nimg)
                 # credits go back in batches of half a ring: each write to the socket may wake
                 # the owner, and a wake-up costs more than the copy
@@ -248,11 +257,13 @@ class NodeGather(object):
                         pass                              # its owner has finished and gone
                     self.owed[i] = 0
             else:
-                all_lengths.extend(np.frombuffer(h[3], np.int32).tolist())
-                dst[at:at + nbytes] = np.frombuffer(h[4], np.uint8)
+                parts.append(np.frombuffer(h[4], np.int32))
+                dst[at:at + nbytes] = np.frombuffer(h[5], np.uint8)
             at += nbytes
         del dst
-        return out, all_lengths
+        self.last_tags = [int(tag)] + [h[3] for h in heads]
+        all_lengths = np.concatenate(parts).tolist()
+        return (memoryview(out)[:total] if out is into else out), all_lengths
 
     def close(self):
         for conn in self.peers:

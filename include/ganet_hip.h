@@ -115,7 +115,7 @@ typedef struct {
                                slower than 2 on MI355X so far);
                                4 = algorithm 2 as ONE launch with the per-tap
                                products kept in the forming XCD's L2 (formed tap by
-                               tap into a two-plane ring that is overwritten in
+                               tap into a three-plane ring that is overwritten in
                                place; 16-bit arithmetic, Cin 64/128/256, Cout <= 64,
                                "same" output size, <= 16 taps, H*W <= 4096; needs
                                the 8 x 32-CU layout of MI355X).

@@ -124,10 +124,15 @@ def _node_worker(rank, world, key, B, steps, q, block_bytes):
         for step in range(steps):
             lo, hi = sharding.shard_range(B, rank, world)
             texts = [("s%d i%d\n" % (step, b) * (b % 3)).encode() for b in range(lo, hi)]
-            res = g.gather(b"".join(texts), [len(t) for t in texts])
+            # odd steps: into a buffer that rank 0 keeps (the text is then a view of it)
+            keep = bytearray(4096) if step % 2 else None
+            res = g.gather(b"".join(texts), [len(t) for t in texts], tag=100 * step + rank, into=keep)
             assert (res is None) == (rank != 0)
             if rank == 0:
-                got.append(res)
+                assert g.last_tags == [100 * step + r for r in range(world)]
+                if keep is not None:
+                    assert isinstance(res[0], memoryview) and res[0].obj is keep
+                got.append((bytes(res[0]), res[1]))
         if rank == 0:
             q.put(got)
     finally:
