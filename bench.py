@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--device-pack", action="store_true",
                     help="pack in device memory and copy D2H (default: the pack kernel "
                          "writes the pinned host block directly)")
+    ap.add_argument("--lfa-priority", action="store_true",
+                    help="run the LFA on a high-priority stream (the decode beside it keeps the default "
+                         "priority and fills what the LFA leaves idle)")
     ap.add_argument("--graph-fork", action="store_true",
                     help="with --graph: record the LFA and the decode as two branches of the graph "
                          "(measured slower at batch 1)")
@@ -357,6 +360,8 @@ def main():
         local_rank = int(os.environ["GANET_BENCH_DEVICE"])
     backend = os.environ.get("GANET_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
+    if args.lfa_priority:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     dev = torch.device("cuda", local_rank)
     dist = None
     # GANET_BENCH_FORCE_DIST: rehearsal of the RCCL rendezvous / barrier / max with one rank

@@ -1140,8 +1140,8 @@ int make_bwd_plan(const ganet_dcn_params *p_in, BwdPlan *pl) {
     // Y and grad_Y of a chunk: with the scatter binned in LDS, fewer and larger launches beat
     // keeping both inside the Infinity Cache (B=32: 96 MB 1.05 ms, 128 MB 0.95, 256 MB 0.91)
     size_t budget = 256ull << 20;
-    if (const char *e = getenv("GANET_BWD_BUDGET_MB")) {   // A/B knob: query and call must agree
-      const long long mb = atoll(e);
+    if (const char *e = getenv("GANET_BWD_BUDGET_MB")) {   // A/B knob, read per call: the call sizes
+      const long long mb = atoll(e);                       // its own need and refuses a smaller workspace
       if (mb > 0) budget = (size_t)mb << 20;
     }
     size_t nb = budget / per_img;

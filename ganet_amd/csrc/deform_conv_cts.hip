@@ -1205,8 +1205,13 @@ int cts_chunk_images(const ganet_dcn_params *p, int CoutP, int ta, bool split) {
   const size_t es = ta == GANET_F32 ? 4 : 2;
   const size_t hw = (size_t)p->H * p->W;
   const size_t per_img = hw * p->kH * p->kW * CoutP * es;
-  size_t budget = 144ull << 20;
-  if (const char *e = getenv("GANET_CTS_BUDGET_MB")) budget = (size_t)atoi(e) << 20;
+  // (a knob that sizes the workspace is read ONCE per process: a query and the call it sizes
+  // can then never see two values)
+  static const size_t budget = [] {
+    const char *e = getenv("GANET_CTS_BUDGET_MB");
+    const long long mb = e ? atoll(e) : 0;
+    return mb > 0 ? (size_t)mb << 20 : (size_t)144 << 20;
+  }();
   size_t nmax = budget / (per_img ? per_img : 1);
   if (nmax < 1) nmax = 1;
   if (nmax > (size_t)p->B) nmax = p->B;

@@ -630,7 +630,7 @@ size_t stream_img_bytes(const ganet_dcn_params *p, int CoutP) {
 // images whose Y one launch holds
 int stream_chunk_images(const ganet_dcn_params *p, int CoutP) {
   const size_t per_img = stream_img_bytes(p, CoutP);
-  const size_t budget = (size_t)env_int("GANET_STREAM_Y_MB", 1024) << 20;
+  static const size_t budget = (size_t)env_int("GANET_STREAM_Y_MB", 1024) << 20;   // once per process
   size_t n = budget / (per_img ? per_img : 1);
   if (n < (size_t)NQ) n = NQ;
   if (n > (size_t)p->B) n = p->B;

@@ -11,8 +11,8 @@
  * synchronises with the host, and enqueues only on the stream it is given.
  * All entry points are re-entrant; the only state the library keeps between calls
  * is the per-GPU address of the static scratch array of ganet_decode_batch_noalloc.
- * A few measurement knobs are read from the environment on every call (INTEGRATION.md,
- * "Build, limits"): a workspace query and the call it sizes must see the same values.
+ * A few measurement knobs are read from the environment ("Build, limits");
+ * those that size a workspace are read once per process: set them before the first call.
  * Call them from one host thread per GPU with that GPU current.
  * Forward AND backward of the operators are here (ganet_deform_conv_backward), plus
  * host-only routines that turn decoded records into the reference's result formats.

@@ -118,14 +118,6 @@ def main():
     if os.environ.get("ONLY4"):
         o4, ctl, t4 = run(xt, pt, wt, K, 4, iters)
         print("algo 4 only: %.4f ms" % t4, describe(ctl), flush=True)
-        if os.environ.get("STAMPS"):
-            st = ctl[96 + 24 * 32:96 + 24 * 32 + 16].view(np.uint64).astype(np.float64)
-            names = ["prologue", "mfma+cvt", "team barrier", "stage+store+gather+blend", "image edge",
-                     "drain+arrive", "-", "-"]
-            tot = st.sum()
-            print("  per-wave phase time (us at 2.1 GHz), share:")
-            for nme, v in zip(names, st):
-                print("   %-26s %8.1f  %5.1f%%" % (nme, v / 4096 / 2100.0 / (iters + 11), 100 * v / max(tot, 1)))
         return
     o2, _, t2 = run(xt, pt, wt, K, 2, iters)
     print("algo 2: %.4f ms" % t2, flush=True)
