@@ -274,7 +274,8 @@ def fuzz_lfa(rng, n):
         H, W, B = int(rng.integers(1, 48)), int(rng.integers(K, 110)), int(rng.integers(1, 40))   # W >= K: the reference refuses narrower maps
         dtype = [torch.float32, torch.bfloat16, torch.bfloat16, torch.float16][int(rng.integers(0, 4))]
         algos = [0, 1] + ([2] if 2 * Cout <= Cin else []) + \
-            ([3] if 2 * Cout <= Cin and Cout == 64 and dtype != torch.float32 else [])
+            ([3] if 2 * Cout <= Cin and Cout == 64 and dtype != torch.float32 else []) + \
+            ([4] if 2 * Cout <= Cin and Cout == 64 and dtype != torch.float32 and H * W <= 4096 else [])
         algo = int(rng.choice(algos))
         nhwc, relu, points = rng.random() < 0.7, rng.random() < 0.5, rng.random() < 0.5
         x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
