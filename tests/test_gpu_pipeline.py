@@ -85,9 +85,20 @@ def test_pack_paths_and_graph_replay_agree():
     assert np.array_equal(r_host.header, r_g.header)
     assert np.array_equal(r_host.records, r_g.records)
     assert torch.equal(hp.feature, feat)
+    # the same step recorded as two branches (LFA | decode) of one graph
+    hp3, _ = build(B, torch.bfloat16)
+    forked = hp3.capture(d["x"], d["pts"], d["heat"], d["off"], d["err"], fork=True)
+    hp3.feature.zero_()
+    forked.replay()
+    r_f = hp3.result()
+    assert np.array_equal(r_host.header, r_f.header) and np.array_equal(r_host.records, r_f.records)
+    assert torch.equal(hp3.feature, feat)
     d["heat"].mul_(0.45)    # the weaker lane points drop below the threshold
     graph.replay()
     r_g2 = hp.result()
+    forked.replay()
+    r_f2 = hp3.result()
+    assert np.array_equal(r_g2.header, r_f2.header) and np.array_equal(r_g2.records, r_f2.records)
     hp2.step(d["x"], d["pts"], d["heat"], d["off"], d["err"])
     r_d2 = hp2.result()
     assert np.array_equal(r_g2.header, r_d2.header)
