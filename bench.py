@@ -711,6 +711,9 @@ def main():
                                                      "%d-th" % args.gather_every))
                                   if gather_thread is not None else
                                   ("none (one rank)" if world == 1 else "off")),
+                       "inputs": "the same HBM-resident synthetic tensors every step (x: %.0f MB per rank, "
+                                 "Infinity Cache 256 MiB); %d untimed spin-up steps before the %d warm-up steps"
+                                 % (d["x"].numel() * d["x"].element_size() / 1e6, spinup, args.warmup),
                        "parallelism": "image-sharded x%d, no collective on the data path" % world},
             "roofline": roof,
             "lfa_ms": lfa_ms,

@@ -15,12 +15,20 @@
 //                        x-major by a rank sort in LDS, greedy centre clustering on one
 //                        wavefront (order dependent, so serial over centres, lane
 //                        parallel over earlier centres), integer means, and the
-//                        first-match keypoint -> centre assignment in float64.
+//                        first-match keypoint -> centre assignment in float64.  With
+//                        DecodeArgs::packed (ganet_decode_batch_packed) it also writes
+//                        the image's record of the host stream itself: one launch.
+//   decode_gather_kernel / decode_assign_kernel   large by-centre images: the keypoint
+//                        lists and the keypoint -> centre assignment on grids over the
+//                        batch; decode_pack_kernel: the record stream as a pass of its own.
 //
 // Bit-exactness notes (all arithmetic below is IEEE, file built with
 // -ffp-contract=off, no fast-math):
 //   * thresholds are compared in float32 like torch does for Python scalars;
-//   * distances use float64 sub / mul / add / sqrt (correctly rounded on CDNA4);
+//   * distances use float64 sub / mul / add; `sqrt(u) <= thr` is decided as `u <= U` with
+//     U = the largest double whose correctly rounded root is <= thr (sqrt_le_bound, found on
+//     the host): the same decisions, no root in the loops; the nearest-centre variant, which
+//     compares distances, still takes the root (correctly rounded on CDNA4);
 //     the reference squares with libm pow(x, 2.0), which is 1 ulp off x*x for a
 //     fraction of a percent of inexact squares - a decision can differ only when a
 //     distance lies within an ulp of the threshold without being exact

@@ -1,7 +1,9 @@
 // Deformable convolution forward for gfx950 (MI355X): the Lane-aware Feature
 // Aggregator's gather-and-aggregate as ONE fused kernel - bilinear sampling of a
 // channel-last feature map straight into an LDS tile, contracted on the matrix
-// cores (exact-fp32 MFMA 32x32x2, or bf16 / f16 MFMA 32x32x16 with fp32 accumulate).
+// cores (bf16 / f16 MFMA 32x32x16 with fp32 accumulate; float32 tensors as three bf16 passes
+// over hi/lo planes of the blended tile - SPLIT below - or, on request, the exact-fp32 MFMA
+// 32x32x2).
 //
 // Restates (arithmetic, not structure)
 //   deformable_im2col_gpu_kernel / _bilinear

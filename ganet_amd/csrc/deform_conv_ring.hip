@@ -14,7 +14,10 @@
 //     staged in LDS two steps ahead as ready-made 16x16x32 operand images, double buffered)
 //     and stores its 16 pixels of plane m (128 B per pixel) into slot m % 3 of the team's
 //     ring: three planes of 2 * H*W*128 B, the same 3 MB of addresses for every tap and every
-//     image, so the lines are dirtied again in L2 instead of being written back;
+//     image - the intent was that the lines are dirtied again in L2 instead of being written
+//     back; MEASURED: every stored byte leaves L2 all the same (WRITE_SIZE = all of Y), only
+//     the way back is saved, and the launch is slower than algorithm 2
+//     (profiles/r03_algo4_notes.txt): opt-in, kept as the record;
 //   * in the same step the wave gathers plane m-2 (8 lanes x 16 B per pixel, a corner
 //     outside the map reads 0 through the buffer bounds check) and adds it into the fp32 sums
 //     of the 16 output pixels it owns; sums, x and coordinates stay in registers / LDS across
@@ -33,8 +36,9 @@
 // middle.  Nothing is drained inside the loop, and the only workgroup barrier of a step (the
 // weights' double buffer and the arrival need one) stands between the MFMAs and the blend.
 // Visibility: producer and consumer share one L2 by construction (teams are formed per
-// XCC id), Y is stored by plain stores (they stay in L2), every storing wave drains them
-// (s_waitcnt vmcnt(0)) before its workgroup arrives, and every load of Y is an sc1 load
+// XCC id), Y is stored by plain stores (L2 keeps the lines for its readers), every storing
+// wave has seen them complete (the counted wait above) before its workgroup arrives, and every
+// load of Y is an sc1 load
 // (served by L2, never by the CU's L1, which may hold the slot's previous plane).
 // Every wait is bounded; a wait that runs out leaves a non-zero status word, and the waves
 // that see it stop touching memory and only keep their workgroup's barriers.  The last
