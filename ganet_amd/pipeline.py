@@ -237,7 +237,7 @@ class HotPath(object):
         as after `step()`.  fork=True: the LFA and the decode do not depend on one another, so
         they are recorded as two branches of the graph (a second stream forks off the
         capturing one and joins it again).  Measured SLOWER at batch 1 on MI355X / ROCm 7.2
-        (41-53 against 29 us per replay, profiles/r03f_bench_c1_bf16_graph*.json: the two
+        (41-53 against 29 us per replay, profiles/r03g_bench_c1_bf16_graph*.json: the two
         branches run on two hardware queues and the fork and the join cost more than the
         17 us of overlap they buy), hence off by default."""
         assert not self.overlap_copy and self.side is None, "capture needs the single-stream flow"
