@@ -616,9 +616,12 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       if (!a.packed) return;
       const int ngs = min(ng_now, a.max_groups);
       rec.words = 7 * nk_st + 3 * nc + (a.by_center_thr >= 0 ? 2 * ngs : 0) + ngs;
-      if (tid == 0) s_rec = atomicAdd(a.pack_ctr, (unsigned long long)rec.words);
-      __syncthreads();
-      const unsigned long long off = s_rec;
+      unsigned long long off = 0;          // a batch of one: the record starts the stream
+      if (a.B > 1) {
+        if (tid == 0) s_rec = atomicAdd(a.pack_ctr, (unsigned long long)rec.words);
+        __syncthreads();
+        off = s_rec;
+      }
       rec.fits = (unsigned long long)a.B * 8 + off + (unsigned long long)rec.words <=
                  (unsigned long long)a.packed_words;
       rec.off = (int)(off < 0x7fffffffull ? off : 0x7fffffffull);
@@ -830,7 +833,9 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       if (b != 0) hdr[6] = 0;
       hdr[7] = 0;
       // the last image to get here knows the total (every image took its words before)
-      if (atomicAdd(a.pack_ctr + 1, 1ull) == (unsigned long long)(a.B - 1)) {
+      if (a.B == 1) {
+        a.packed[6] = rec.words;
+      } else if (atomicAdd(a.pack_ctr + 1, 1ull) == (unsigned long long)(a.B - 1)) {
         const unsigned long long total = atomicExch(a.pack_ctr, 0ull);
         atomicExch(a.pack_ctr + 1, 0ull);
         a.packed[6] = (int)(total < 0x7fffffffull ? total : 0x7fffffffull);
