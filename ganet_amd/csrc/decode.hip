@@ -659,7 +659,27 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     // i.e. the smallest group index among earlier centres within thr.
     const double T = a.by_center_thr;
     const double U = a.by_center_sq;
-    if (wid == 0) {
+    if (wid == 0 && nc <= 64) {
+      // up to 64 centres (every lane image the configs produce): lane j keeps centre j and,
+      // as lane g, the members of group g as a 64-bit set.  Centre i joins the lowest group
+      // that holds an earlier centre within thr: one ballot for "who is near", one for "which
+      // groups hold one of those", find-first-set - no reduction, no LDS in the loop.
+      const unsigned int kj = lane < nc ? ckey[lane] : 0u;
+      const int xj = (int)(kj >> 16), yj = (int)(kj & 0xffffu);
+      unsigned long long members = 0ull;
+      int mine = 0, ngl = 0;
+      for (int i = 0; i < nc; ++i) {
+        const int xi = __builtin_amdgcn_readlane(xj, i), yi = __builtin_amdgcn_readlane(yj, i);
+        const double dx = (double)(xi - xj), dy = (double)(yi - yj);
+        const unsigned long long near = __ballot(lane < i && dx * dx + dy * dy <= U);
+        const unsigned long long hit = __ballot((members & near) != 0ull);
+        const int g = hit ? __ffsll((long long)hit) - 1 : ngl++;
+        if (lane == g) members |= 1ull << i;
+        if (lane == i) mine = g;
+      }
+      if (lane < nc) cgid[lane] = mine;
+      if (lane == 0) s_ng = ngl;
+    } else if (wid == 0) {
       int ngl = 0;
       for (int i = 0; i < nc; ++i) {
         const unsigned int ki = ckey[i];
