@@ -609,8 +609,14 @@ def main():
             one_step(events[i])
         torch.cuda.synchronize()
     timed = [e for e in events if e is not None]
-    lfa_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in timed]))
-    dec_ms = float(np.mean([e[3].elapsed_time(e[2]) for e in timed])) if wl["decode"] else 0.0
+    lfa_all = np.array([e[0].elapsed_time(e[1]) for e in timed])
+    dec_all = np.array([e[3].elapsed_time(e[2]) for e in timed]) if wl["decode"] else np.zeros(1)
+    lfa_ms = float(lfa_all.mean())
+    dec_ms = float(dec_all.mean()) if wl["decode"] else 0.0
+
+    def spread(a):      # median and the 10th / 90th percentile of the bracketed steps
+        return {"p10": float(np.percentile(a, 10)), "median": float(np.median(a)),
+                "p90": float(np.percentile(a, 90)), "samples": int(a.size)}
 
     if rank == 0:
         nbytes, flops = lfa_algorithmic(B, Cin, 64, H, W, K, dtype)
@@ -718,6 +724,8 @@ def main():
             "roofline": roof,
             "lfa_ms": lfa_ms,
             "decode_ms": dec_ms,
+            "lfa_ms_spread": spread(lfa_all),
+            "decode_ms_spread": spread(dec_all) if wl["decode"] else None,
             "kernel_time_samples": len(timed),   # steps of the timed region bracketed by events
             "lfa_images_per_s_per_gpu": B / lfa_s,
         }
