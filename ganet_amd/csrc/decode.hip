@@ -571,7 +571,6 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
     ckey[rank] = ki;
   }
   __syncthreads();
-  DSTAMP(5);
   for (int i = tid; i < nc; i += kBlock) {
     o_cxy[2 * i] = (int)(ckey[i] >> 16);
     o_cxy[2 * i + 1] = (int)(ckey[i] & 0xffffu);
@@ -608,6 +607,7 @@ __global__ __launch_bounds__(kBlock) void decode_group_kernel(DecodeArgs a) {
       ckey[i] = ((unsigned int)o_cxy[2 * i] << 16) | (unsigned int)o_cxy[2 * i + 1];
     __syncthreads();
   }
+  DSTAMP(5);    // every mode: the centre list stands sorted in LDS
   int ng = 0;
   RecordSlot rec = {nullptr, 0, 0, true};
   // block-uniform; called once, when the number of groups is known
