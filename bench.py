@@ -622,7 +622,7 @@ def main():
         nbytes, flops = lfa_algorithmic(B, Cin, 64, H, W, K, dtype)
         # float32 tensors on algorithms 1 and 2 are contracted as three bf16 MFMA passes
         # (hi*hi + hi*lo + lo*hi): price the matrix work as 3x the FLOPs at the bf16 peak
-        split = dtype == "fp32" and hp.lfa_algorithm in (1, 2) and args.fp32_mode == "auto"
+        split = dtype == "fp32" and hp.lfa_algorithm in (1, 2, 5) and args.fp32_mode == "auto"
         arith = dtype
         if split:
             flops *= 3.0
@@ -669,6 +669,7 @@ def main():
         kernels = ("dcn_fused_kernel" if hp.lfa_algorithm == 1 else
                    "lfa_stream_kernel" if hp.lfa_algorithm == 3 else
                    "lfa_ring_kernel" if hp.lfa_algorithm == 4 else
+                   "dcn_taps_kernel" if hp.lfa_algorithm == 5 else
                    "%s + cts_sample_kernel (all chunk pairs of one LFA launch)"
                    % ("cts_gemm_split_kernel" if split else
                       "cts_gemm_ov_kernel" if dtype != "fp32" and Cin in (64, 128, 256)

@@ -33,6 +33,7 @@ def _variant_flags():
     extra = ["-DGANET_ABLATE"] if os.environ.get("GANET_ABLATE") else []  # profiling build
     extra += os.environ.get("GANET_RING_DEFS", "").split()      # -DGANET_RING_... (ablations)
     extra += os.environ.get("GANET_DECODE_DEFS", "").split()    # -DGANET_DECODE_STAMPS
+    extra += os.environ.get("GANET_TAPS_DEFS", "").split()      # -DGANET_TAPS_STAMPS
     if os.environ.get("GANET_STREAM_DEBUG"):
         extra.append("-DGANET_STREAM_DEBUG")
         extra += os.environ.get("GANET_STREAM_DEFS", "").split()
@@ -41,7 +42,7 @@ def _variant_flags():
 
 def build_lib(force=False, verbose=False):
     """The product library; with variant flags in the environment (GANET_ABLATE, GANET_RING_DEFS,
-    GANET_DECODE_DEFS, GANET_STREAM_DEBUG) a SEPARATE library libganet_hip_<tag>.so with objects of
+    GANET_DECODE_DEFS, GANET_TAPS_DEFS, GANET_STREAM_DEBUG) a SEPARATE library libganet_hip_<tag>.so with objects of
     its own, so that a debug or ablation build can never be picked up as the product library
     afterwards (load it with GANET_HIP_LIB=<path>)."""
     global LIB, OBJ_DIR
@@ -65,7 +66,7 @@ def build_lib(force=False, verbose=False):
     objs, relink = [], force or not os.path.exists(LIB)
     # flags named after one source file only rebuild that file; the rest are the product's objects
     only = {"-DGANET_RING": "deform_conv_ring.hip", "-DGANET_STREAM": "deform_conv_stream.hip",
-            "-DGANET_DECODE": "decode.hip"}
+            "-DGANET_DECODE": "decode.hip", "-DGANET_TAPS": "deform_conv.hip"}
     touched = {v for f in extra for k, v in only.items() if f.startswith(k)}
     narrow = bool(extra) and all(any(f.startswith(k) for k in only) for f in extra)
     if narrow:

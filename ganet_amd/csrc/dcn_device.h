@@ -69,6 +69,7 @@ struct DcnArgs {
   const float *offset;  // [B][dg*2*T][Ho][Wo]
   const float *mask;    // [B][dg*T][Ho][Wo] or nullptr
   const void *wp;       // packed weights [T][CoutP][Cp]
+  const void *wp_frag;  // their fragment-major copy (algorithm 5)
   const void *bias;     // [Cout] or nullptr
   void *out;
   int B, H, W, Cp, Ho, Wo, Cout, CoutP;

@@ -567,6 +567,312 @@ __global__ __launch_bounds__(NW * 64, 2) void dcn_fused_kernel(DcnArgs a) {
   }
 }
 
+// ---- small batches: the taps of a pixel tile on different wavefronts ----------------------
+// At batch 1 (BASELINE's C1: one 40x100 map, 2 MB of x) nothing is bound by bytes: the
+// contract-then-sample pair is two launches of one memory round trip after another (8.7 +
+// 6.2 us and the gap between them), and dcn_fused_kernel walks a pixel tile's taps and
+// channel chunks one round trip after the other on one wavefront (41 us).  Here a workgroup
+// owns 16 output pixels x 64 outputs and its wavefronts split the TAPS: wave w samples and
+// contracts taps w, w + NWV, ... of the same 16 pixels (NWV = min(taps, 8)), every wave with
+// its own coordinates, gathers, blended tile and weight fragments.  The chain of dependent
+// round trips is offsets -> gathers -> store whatever the number of taps or channels: the
+// weight fragments (read straight from the packed weights in MFMA 16x16x32 layout, no
+// staging, no workgroup barrier in the loop) are requested right behind the offsets, and the
+// gathers of up to four 128-byte channel chunks (all 256 channels of a 16-bit map) are in
+// flight at once.  The partial 16 x 64 blocks meet in LDS and are summed in wave order by
+// the whole workgroup (a fixed order: results are bit-identical from run to run), which also
+// gives coalesced stores for both output layouts.  One deformable group; float32 tensors in
+// the hi/lo three-pass form only.
+constexpr int TAPS_WAVES = 8;
+constexpr int TAPS_PIX = 16;
+#ifdef GANET_TAPS_STAMPS
+// wall-clock stamps (10 ns) of the first and last wave of the first and last workgroup:
+// start, coordinates in the table, gathers issued, chunk 0 contracted (one per DEPTH chunks),
+// block parked, barrier passed, outputs stored (tools/taps_stamps.py)
+__device__ long long g_taps_stamps[4][12];
+#endif
+
+template <typename TM>
+struct Mma16;
+template <>
+struct Mma16<bf16_t> {
+  __device__ static __forceinline__ void mma(const bf16x8 &a, const bf16x8 &b, f32x4 &c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma16<f16_t> {
+  __device__ static __forceinline__ void mma(const f16x8 &a, const f16x8 &b, f32x4 &c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename TA, typename TO, bool SPLIT>
+__global__ __launch_bounds__(TAPS_WAVES * 64) void dcn_taps_kernel(DcnArgs a) {
+  static_assert(SPLIT == (sizeof(TA) == 4), "float32 tensors take the split form, 16-bit ones the plain one");
+  using TM = typename std::conditional<SPLIT, bf16_t, TA>::type;
+  constexpr int ES = sizeof(TA);
+  constexpr int EPL = 16 / ES;
+  constexpr int KC = 128 / ES;                          // gather chunk: 128 B of channels per pixel
+  constexpr int LPP = 8;                                // lanes per pixel chunk
+  constexpr int PPL = 8;                                // pixels per load instruction
+  constexpr int NPASS = TAPS_PIX / PPL;                 // load passes per chunk
+  constexpr int DEPTH = 4;                              // chunks whose gathers are in flight
+  constexpr int PLANES = SPLIT ? 2 : 1;
+  constexpr int LDA = PLANES * KC + 8;                  // 16-bit elements; +16 B: conflict-free b128 reads
+  constexpr int NKS = KC / 32;                          // MFMA K steps (32 channels) per chunk
+  constexpr int A_BYTES = TAPS_PIX * LDA * 2;
+  constexpr int RROW = 65;                              // floats per pixel row of a partial block
+  constexpr int R_BYTES = TAPS_PIX * RROW * 4;
+  constexpr int W_BYTES = (2 * A_BYTES > R_BYTES ? 2 * A_BYTES : R_BYTES);   // per wave: two tiles / one block
+  typedef typename Mma<TM>::frag frag_t;
+  __shared__ __attribute__((aligned(16))) unsigned char s_t[TAPS_WAVES * W_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned int s_off[TAPS_WAVES][TAPS_PIX][4];
+  __shared__ __attribute__((aligned(16))) float s_w[TAPS_WAVES][TAPS_PIX][4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwv = (int)(blockDim.x >> 6);
+  const long long tile = blockIdx.x;
+  const int n0 = blockIdx.y * TN;
+  const int HWo = a.Ho * a.Wo;
+  const int T = a.kH * a.kW;
+  const TM *wp = static_cast<const TM *>(a.wp_frag);   // the fragment-major copy (frag_major_index)
+  const size_t w_plane = (size_t)T * a.CoutP * a.Cp;
+  TM *A0 = reinterpret_cast<TM *>(s_t + wid * W_BYTES);
+  TM *A1 = reinterpret_cast<TM *>(s_t + wid * W_BYTES + A_BYTES);
+
+  // buffer window as in dcn_fused_kernel: from the first image the tile touches, below 2 GiB
+  const int b0 = (int)((tile * TAPS_PIX) / HWo);
+  const size_t img_bytes = (size_t)a.H * a.W * a.Cp * ES;
+  const size_t win_rest = (size_t)(a.B - b0) * img_bytes;
+  const unsigned win_bytes = win_rest < 0x7fffffffull ? (unsigned)win_rest : 0x7fffffffu;
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char *>(static_cast<const unsigned char *>(a.xh)) + (size_t)b0 * img_bytes,
+      0, (int)win_bytes, 0x00020000);
+
+  const int lp = lane % LPP, pq = lane / LPP;
+  const int i = lane & 15, kg = lane >> 4;            // MFMA 16x16x32: row / column i, K group kg
+  const long long my_p = tile * TAPS_PIX + i;
+  const bool my_valid = my_p < a.P;
+  const int my_b = my_valid ? (int)(my_p / HWo) : 0;
+  const int my_hw = my_valid ? (int)(my_p - (long long)my_b * HWo) : 0;
+  const int my_ho = my_hw / a.Wo, my_wo = my_hw - my_ho * a.Wo;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // sampling position of (pixel i, tap t): corner offsets inside the window and the four
+  // bilinear weights (times the DCNv2 mask) -> this wave's table
+  // (deform_conv_cuda_kernel.cu:84-115, :227-229; lanepoints_conv.py:63-74,170 for `points`)
+  auto load_offsets = [&](int t, float &off_h, float &off_w, float &mk) {
+    off_h = 0.f;
+    off_w = 0.f;
+    mk = 1.f;
+    if (lane < TAPS_PIX && my_valid) {
+      const float *op = a.offset + ((size_t)my_b * 2 * T + 2 * t) * HWo + my_hw;
+      off_h = ldg_f32(op);
+      off_w = ldg_f32(op + HWo);
+      if (a.mask) mk = ldg_f32(a.mask + ((size_t)my_b * T + t) * HWo + my_hw);
+    }
+  };
+  auto coords = [&](int t, float off_h, float off_w, float mk) {
+    if (lane < TAPS_PIX) {
+      const int ti = t / a.kW, tj = t - ti * a.kW;
+      unsigned c1 = OOB_OFFSET, c2 = OOB_OFFSET, c3 = OOB_OFFSET, c4 = OOB_OFFSET;
+      float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+      if (my_valid) {
+        if (a.points) off_w = off_w - (float)(tj - a.pW);
+        const float h_im = (float)(my_ho * a.sH - a.pH + ti * a.dH) + off_h;
+        const float w_im = (float)(my_wo * a.sW - a.pW + tj * a.dW) + off_w;
+        if (h_im > -1 && w_im > -1 && h_im < a.H && w_im < a.W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const int h_high = h_low + 1, w_high = w_low + 1;
+          const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+          const float hh = 1.f - lh, hw_ = 1.f - lw;
+          w1 = hh * hw_;
+          w2 = hh * lw;
+          w3 = lh * hw_;
+          w4 = lh * lw;
+          const unsigned px = (unsigned)(a.Cp * ES);
+          const unsigned row = (unsigned)a.W * px;
+          const unsigned base = (unsigned)(my_b - b0) * (unsigned)img_bytes +
+                                (unsigned)h_low * row + (unsigned)w_low * px;
+          const bool hl = h_low >= 0, hh_ok = h_high <= a.H - 1;
+          const bool wl = w_low >= 0, wh_ok = w_high <= a.W - 1;
+          if (hl && wl) c1 = base;
+          if (hl && wh_ok) c2 = base + px;
+          if (hh_ok && wl) c3 = base + row;
+          if (hh_ok && wh_ok) c4 = base + row + px;
+        }
+      }
+      *reinterpret_cast<uint4 *>(s_off[wid][lane]) = make_uint4(c1, c2, c3, c4);
+      *reinterpret_cast<float4 *>(s_w[wid][lane]) = make_float4(w1 * mk, w2 * mk, w3 * mk, w4 * mk);
+    }
+  };
+  auto issue = [&](u32x4 (&v)[NPASS][4], int cabs) {
+    const unsigned lane_off = (unsigned)((cabs + lp * EPL) * ES);
+#pragma unroll
+    for (int u = 0; u < NPASS; ++u) {
+      const uint4 cx = *reinterpret_cast<const uint4 *>(s_off[wid][u * PPL + pq]);
+      v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.x + lane_off, 0, 0);
+      v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.y + lane_off, 0, 0);
+      v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.z + lane_off, 0, 0);
+      v[u][3] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, cx.w + lane_off, 0, 0);
+    }
+  };
+  auto blend = [&](u32x4 (&v)[NPASS][4], TM *Adst) {
+#pragma unroll
+    for (int u = 0; u < NPASS; ++u) {
+      const int r = u * PPL + pq;
+      const float4 w = *reinterpret_cast<const float4 *>(s_w[wid][r]);
+      const u32x4 o = Blend<TA>::run(v[u], w);
+      if constexpr (SPLIT) {
+        // hi = the upper 16 bits, lo = the rest rounded to nearest even, integer operations
+        // only (see the note in dcn_fused_kernel's blend)
+        uint2 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float x0 = __uint_as_float(o[2 * k]), x1 = __uint_as_float(o[2 * k + 1]);
+          const unsigned int u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+          const unsigned int h0 = u0 & 0xffff0000u, h1 = u1 & 0xffff0000u;
+          const unsigned int l0 = __float_as_uint(x0 - __uint_as_float(h0));
+          const unsigned int l1 = __float_as_uint(x1 - __uint_as_float(h1));
+          const unsigned int r0 = l0 + 0x7fffu + ((l0 >> 16) & 1u);
+          const unsigned int r1 = l1 + 0x7fffu + ((l1 >> 16) & 1u);
+          (k == 0 ? hi.x : hi.y) = (h0 >> 16) | h1;
+          (k == 0 ? lo.x : lo.y) = (r0 >> 16) | (r1 & 0xffff0000u);
+        }
+        *reinterpret_cast<uint2 *>(Adst + r * LDA + lp * EPL) = hi;
+        *reinterpret_cast<uint2 *>(Adst + r * LDA + KC + lp * EPL) = lo;
+      } else {
+        *reinterpret_cast<u32x4 *>(Adst + r * LDA + lp * EPL) = o;
+      }
+    }
+  };
+  // weight fragments of (tap t, channels cabs ..): lane (i, kg) supplies row n0 + 16 nb + i,
+  // channels 32 ks + 8 kg .. + 8, 1 KB in a row per instruction from the fragment-major copy
+  auto load_w = [&](frag_t (&wf)[PLANES][NKS][4], int t, int cabs) {
+    const size_t blk = ((size_t)t * (a.Cp / 32) + cabs / 32) * (a.CoutP / 16) + n0 / 16;
+#pragma unroll
+    for (int pn = 0; pn < PLANES; ++pn)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          wf[pn][ks][nb] = __builtin_bit_cast(
+              frag_t, ldg128(wp + pn * w_plane +
+                             ((blk + (size_t)ks * (a.CoutP / 16) + nb) * 64 + lane) * 8));
+  };
+  auto contract = [&](const TM *Acur, const frag_t (&wf)[PLANES][NKS][4]) {
+    const TM *arow = Acur + i * LDA + kg * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const frag_t ah = *reinterpret_cast<const frag_t *>(arow + ks * 32);
+      if constexpr (SPLIT) {
+        const frag_t al = *reinterpret_cast<const frag_t *>(arow + KC + ks * 32);
+        // small terms first, as in dcn_fused_kernel
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) Mma16<TM>::mma(al, wf[0][ks][nb], acc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) Mma16<TM>::mma(ah, wf[PLANES - 1][ks][nb], acc[nb]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) Mma16<TM>::mma(ah, wf[0][ks][nb], acc[nb]);
+    }
+  };
+
+#ifdef GANET_TAPS_STAMPS   // profiling build (GANET_TAPS_DEFS=-DGANET_TAPS_STAMPS): phase times of four waves
+  const int stamp_b = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : -1);
+  const int stamp_w = wid == 0 ? 0 : (wid == nwv - 1 ? 1 : -1);
+  const int stamp_slot = (stamp_b < 0 || stamp_w < 0) ? -1 : stamp_b + stamp_w;
+  int nts = 0;
+#define TAPS_STAMP() do { if (stamp_slot >= 0 && lane == 0 && nts < 12) g_taps_stamps[stamp_slot][nts++] = wall_clock64(); } while (0)
+#else
+#define TAPS_STAMP() do { } while (0)
+#endif
+  TAPS_STAMP();
+  const int NCH = a.Cp / KC;
+  u32x4 v0[NPASS][4], v1[NPASS][4], v2[NPASS][4], v3[NPASS][4];
+  frag_t wa[PLANES][NKS][4], wb[PLANES][NKS][4];
+  // chunk c of tap t: its gathers sit in `v` (issued DEPTH chunks ago), its weights in `wcur`;
+  // the register sets it frees are refilled with chunk c + DEPTH's gathers and chunk c + 2's weights
+  auto step = [&](int t, int c, u32x4 (&v)[NPASS][4], TM *Adst, frag_t (&wcur)[PLANES][NKS][4]) {
+    blend(v, Adst);
+    if (c + DEPTH < NCH) issue(v, (c + DEPTH) * KC);
+    wave_lds_sync();
+    contract(Adst, wcur);
+    if (c + 2 < NCH) load_w(wcur, t, (c + 2) * KC);
+  };
+  for (int t = wid; t < T; t += nwv) {
+    float off_h, off_w, mk;
+    load_offsets(t, off_h, off_w, mk);     // first in the queue: loads come back in order
+    load_w(wa, t, 0);                      // nothing they depend on: under the offsets' round trip
+    if (1 < NCH) load_w(wb, t, KC);
+    wave_lds_sync();                       // the table's readers of the previous tap are done
+    coords(t, off_h, off_w, mk);
+    wave_lds_sync();
+    TAPS_STAMP();
+    issue(v0, 0);
+    if (1 < NCH) issue(v1, KC);
+    if (2 < NCH) issue(v2, 2 * KC);
+    if (3 < NCH) issue(v3, 3 * KC);
+    TAPS_STAMP();
+    for (int c = 0; c < NCH; c += DEPTH) {
+      step(t, c, v0, A0, wa);
+      TAPS_STAMP();
+      if (c + 1 < NCH) step(t, c + 1, v1, A1, wb);
+      if (c + 2 < NCH) step(t, c + 2, v2, A0, wa);
+      if (c + 3 < NCH) step(t, c + 3, v3, A1, wb);
+    }
+  }
+  wave_lds_sync();
+
+  // ---- partial blocks meet in LDS: [pixel][output], one per wave ------------------------
+  // accumulator map (16x16, block nb): column = 16 nb + i (output), row = 4 kg + reg (pixel)
+  float *Rs = reinterpret_cast<float *>(s_t + wid * W_BYTES);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rs[(4 * kg + r) * RROW + nb * 16 + i] = acc[nb][r];
+  TAPS_STAMP();
+  __syncthreads();
+  TAPS_STAMP();
+  TO *out = static_cast<TO *>(a.out);
+  const TO *bias = static_cast<const TO *>(a.bias);
+  const int nthr = nwv * 64;
+  for (int e = tid; e < TAPS_PIX * 64; e += nthr) {
+    // consecutive threads: consecutive outputs (channel-last) or consecutive pixels (NCHW)
+    const int pix = a.out_nhwc ? e >> 6 : e & (TAPS_PIX - 1);
+    const int c = a.out_nhwc ? e & 63 : e / TAPS_PIX;
+    const long long p = tile * TAPS_PIX + pix;
+    const int oc = n0 + c;
+    if (p >= a.P || oc >= a.Cout) continue;
+    // all partials requested at once (a loop over nwv would pay one LDS latency per wave),
+    // added in wave order; absent waves add nothing (not even a zero: -0 stays -0)
+    float part[TAPS_WAVES];
+#pragma unroll
+    for (int w = 0; w < TAPS_WAVES; ++w)
+      part[w] = w < nwv ? *reinterpret_cast<const float *>(s_t + w * W_BYTES + pix * RROW * 4 + c * 4)
+                        : 0.f;
+    float sum = part[0];
+#pragma unroll
+    for (int w = 1; w < TAPS_WAVES; ++w) sum = w < nwv ? sum + part[w] : sum;
+    if (bias) sum += to_f32(bias[oc]);
+    if (a.relu) sum = fmaxf(sum, 0.f);
+    if (a.out_nhwc) {
+      out[p * a.Cout + oc] = from_f32<TO>(sum);
+    } else {
+      const int b = (int)(p / HWo);
+      const int hw = (int)(p - (long long)b * HWo);
+      out[((size_t)b * a.Cout + oc) * HWo + hw] = from_f32<TO>(sum);
+    }
+  }
+  TAPS_STAMP();
+#undef TAPS_STAMP
+}
+
 // ---- layout / packing helpers -----------------------------------------------
 
 // x[B][C][HW] (TS) -> xh[B][HW][Cp] (TD), channels >= C zero-filled.
@@ -617,10 +923,20 @@ __device__ __forceinline__ long long grouped_weight_index(int o, int c, int t, i
   return ((long long)o * cig + cg) * T + t;
 }
 
+// Element (t, o, c) of the fragment-major copy that dcn_taps_kernel reads: blocks of 16 outputs x
+// 32 channels in the order the MFMA 16x16x32 takes them (lane = o % 16 + 16 * (c % 32 / 8), eight
+// channels per lane), so that one load instruction of a wavefront reads 1 KB in a row.
+__device__ __forceinline__ long long frag_major_index(int t, int o, int c, int CoutP, int Cp) {
+  const long long block = ((long long)t * (Cp / 32) + c / 32) * (CoutP / 16) + o / 16;
+  const int lane = (o & 15) + 16 * ((c & 31) >> 3);
+  return (block * 64 + lane) * 8 + (c & 7);
+}
+
+// frag_off: where the fragment-major copy starts (elements of TD), 0 = none
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void pack_weight_kernel(
     const TS *__restrict__ w, TD *__restrict__ wp, int Cout, int Cin, int T,
-    int CoutP, int Cp, int groups) {
+    int CoutP, int Cp, int groups, long long frag_off) {
   const long long total = (long long)T * CoutP * Cp;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
        i += (long long)gridDim.x * 256) {
@@ -633,6 +949,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(
       if (k >= 0) v = to_f32(w[k]);
     }
     wp[i] = from_f32<TD>(v);
+    if (frag_off) wp[frag_off + frag_major_index(t, o, c, CoutP, Cp)] = from_f32<TD>(v);
   }
 }
 
@@ -640,7 +957,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(
 // lo = bf16(w - hi)  (cts_gemm_split_kernel, deform_conv_cts.hip)
 __global__ __launch_bounds__(256) void pack_weight_split_kernel(
     const float *__restrict__ w, bf16_t *__restrict__ wp, int Cout, int Cin, int T,
-    int CoutP, int Cp, int groups) {
+    int CoutP, int Cp, int groups, long long frag_off) {
   const long long total = (long long)T * CoutP * Cp;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
        i += (long long)gridDim.x * 256) {
@@ -653,8 +970,14 @@ __global__ __launch_bounds__(256) void pack_weight_split_kernel(
       if (k >= 0) v = w[k];
     }
     const bf16_t hi = from_f32<bf16_t>(v);
+    const bf16_t lo = from_f32<bf16_t>(v - to_f32(hi));
     wp[i] = hi;
-    wp[total + i] = from_f32<bf16_t>(v - to_f32(hi));
+    wp[total + i] = lo;
+    if (frag_off) {
+      const long long k = frag_off + frag_major_index(t, o, c, CoutP, Cp);
+      wp[k] = hi;
+      wp[total + k] = lo;
+    }
   }
 }
 
@@ -672,12 +995,24 @@ struct Plan {
   bool fsplit;   // the fused kernel with float32 tensors contracted as three bf16 passes
   bool stream;   // ... as one persistent producer/consumer launch (deform_conv_stream.hip)
   bool ring;     // ... as one launch with Y kept in L2, tap-major (deform_conv_ring.hip)
+  bool taps;     // small batches: the taps of a pixel tile on different wavefronts (dcn_taps_kernel)
   bool keep_y;   // the whole batch's per-tap products stay in the workspace (GANET_DCN_ALGO_KEEP_Y)
   int nb;        // images per chunk of the contract-then-sample pair
   size_t xh_bytes, wp_bytes, y_bytes;
+  size_t wp_frag_off;   // the fragment-major copy of the packed weights (bytes into them), 0 = none
 };
 
 size_t dtype_size(int dt) { return dt == GANET_F32 ? 4 : 2; }
+
+// tiles (16 pixels x 64 outputs) up to which algorithm 5 is chosen by itself; GANET_TAPS_MAX_TILES
+// is an A/B knob, read once per process (0 = never)
+long long taps_max_tiles() {
+  static const long long v = [] {
+    const char *e = getenv("GANET_TAPS_MAX_TILES");
+    return e ? atoll(e) : 256ll;
+  }();
+  return v;
+}
 
 int make_plan(const ganet_dcn_params *p_in, Plan *pl) {
   if (!p_in) return GANET_ERR_NULL;
@@ -751,13 +1086,31 @@ int make_plan(const ganet_dcn_params *p_in, Plan *pl) {
                             : 0;
   pl->wp_bytes = ganet_align_up(
       (size_t)pl->T * pl->CoutP * pl->Cp * dtype_size(pl->ta), 256);
+  pl->wp_frag_off = 0;
   // Sampling and contraction commute; contract first when that shrinks the rows
   // that have to be gathered and blended (Cout < Cin, as in the LFA).
-  pl->cts = cts_applicable(p, pl->Cp, pl->CoutP) && p->algo != 1;
-  if (p->algo < 0 || p->algo > 4) return GANET_ERR_BAD_SHAPE;
+  pl->cts = cts_applicable(p, pl->Cp, pl->CoutP) && p->algo != 1 && p->algo != 5;
+  if (p->algo < 0 || p->algo > 5) return GANET_ERR_BAD_SHAPE;
   if (p->algo == 2 && !pl->cts) return GANET_ERR_UNSUPPORTED;
   pl->split = pl->cts && pl->ta == GANET_F32 && cts_split(p, pl->Cp);
   pl->fsplit = !pl->cts && pl->ta == GANET_F32 && p->mfma_bf16 == 0;
+  // Small batches (algorithm 5): one launch whose wavefronts split the taps.  Chosen by itself
+  // while the call is a single round of workgroups (at most taps_max_tiles() tiles of 16 pixels x
+  // 64 outputs) and only where it reads the packed weights the other choice would read (plain
+  // planes for 16-bit arithmetic, hi/lo planes for float32), so that weights packed for a
+  // shape at one batch size serve it at any other.
+  {
+    const long long tiles = ((long long)p->B * pl->Ho * pl->Wo + TAPS_PIX - 1) / TAPS_PIX * (pl->CoutP / TN);
+    const bool can = p->deformable_groups == 1 && !keep_y && !p->debug &&
+                     (pl->ta != GANET_F32 || p->mfma_bf16 == 0);
+    const bool same_pack = pl->ta != GANET_F32 || pl->split || pl->fsplit;
+    if (p->algo == 5 && !can) return GANET_ERR_UNSUPPORTED;
+    pl->taps = can && (p->algo == 5 || (p->algo == 0 && same_pack && tiles <= taps_max_tiles()));
+    if (pl->taps) {
+      pl->cts = pl->split = false;
+      pl->fsplit = pl->ta == GANET_F32;
+    }
+  }
   pl->stream = pl->cts && p->algo == 3 &&
                stream_applicable(p, pl->ta, pl->Cp, pl->CoutP, pl->Ho, pl->Wo);
   if (p->algo == 3 && !pl->stream) return GANET_ERR_UNSUPPORTED;
@@ -774,6 +1127,13 @@ int make_plan(const ganet_dcn_params *p_in, Plan *pl) {
     const unsigned long long img_y = (unsigned long long)p->H * p->W * pl->T * pl->CoutP *
                                      dtype_size(pl->ta);
     if (img_y * (unsigned long long)pl->nb >= 0x7fffffffull) return GANET_ERR_UNSUPPORTED;
+  }
+  // 16-bit planes (plain, or the hi/lo pair of float32 tensors) are packed twice: [tap][Cout][Cin]
+  // for algorithms 1-4 and fragment-major for algorithm 5 - whatever the batch size of `p`, so
+  // that weights packed for a shape at one batch size serve it at any other
+  if (pl->ta != GANET_F32 || pl->split || pl->fsplit) {
+    pl->wp_frag_off = pl->wp_bytes;
+    pl->wp_bytes *= 2;
   }
   pl->y_bytes = pl->stream ? stream_workspace_bytes(p, pl->CoutP)
                 : pl->ring ? ring_workspace_bytes(p)
@@ -807,7 +1167,8 @@ void launch_pack_weight(const ganet_dcn_params *p, const Plan &pl, const void *w
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL((pack_weight_kernel<TS, TD>), dim3(blocks), dim3(256), 0, s,
                      static_cast<const TS *>(w), static_cast<TD *>(wp), p->Cout,
-                     p->Cin, pl.T, pl.CoutP, pl.Cp, p->groups);
+                     p->Cin, pl.T, pl.CoutP, pl.Cp, p->groups,
+                     (long long)(pl.wp_frag_off / sizeof(TD)));
 }
 
 template <typename TA, typename TO, int KCB, bool SPLIT = false>
@@ -860,7 +1221,7 @@ extern "C" size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p) {
 extern "C" int ganet_deform_conv_algorithm(const ganet_dcn_params *p) {
   Plan pl;
   if (!p || make_plan(p, &pl) != GANET_OK) return 0;
-  return pl.ring ? 4 : (pl.stream ? 3 : (pl.cts ? 2 : 1));
+  return pl.taps ? 5 : (pl.ring ? 4 : (pl.stream ? 3 : (pl.cts ? 2 : 1)));
 }
 
 extern "C" size_t ganet_deform_conv_status_offset(const ganet_dcn_params *p) {
@@ -889,7 +1250,8 @@ int pack_weight_dispatch(const ganet_dcn_params *p, const Plan &pl,
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weight_split_kernel, dim3(blocks), dim3(256), 0, s,
                        static_cast<const float *>(weight), static_cast<bf16_t *>(wp),
-                       p->Cout, p->Cin, pl.T, pl.CoutP, pl.Cp, p->groups);
+                       p->Cout, p->Cin, pl.T, pl.CoutP, pl.Cp, p->groups,
+                       (long long)(pl.wp_frag_off / 2));
   } else if (p->dtype == GANET_F32 && pl.ta == GANET_F32)
     launch_pack_weight<float, float>(p, pl, weight, wp, s);
   else if (p->dtype == GANET_F32 && pl.ta == GANET_BF16)
@@ -969,6 +1331,7 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
   a.offset = offset;
   a.mask = mask;
   a.wp = wp;
+  a.wp_frag = static_cast<const unsigned char *>(wp) + pl.wp_frag_off;
   a.bias = bias;
   a.out = out;
   a.B = p->B;
@@ -995,6 +1358,19 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
   a.ablate = p->debug;
   a.P = (long long)p->B * pl.Ho * pl.Wo;
 
+  if (pl.taps) {
+    const int nwv = pl.T < TAPS_WAVES ? pl.T : TAPS_WAVES;
+    const dim3 grid((unsigned)((a.P + TAPS_PIX - 1) / TAPS_PIX), (unsigned)(pl.CoutP / TN)), block(nwv * 64);
+    if (pl.ta == GANET_F32)
+      hipLaunchKernelGGL((dcn_taps_kernel<float, float, true>), grid, block, 0, s, a);
+    else if (pl.ta == GANET_BF16 && p->dtype == GANET_F32)
+      hipLaunchKernelGGL((dcn_taps_kernel<bf16_t, float, false>), grid, block, 0, s, a);
+    else if (pl.ta == GANET_BF16)
+      hipLaunchKernelGGL((dcn_taps_kernel<bf16_t, bf16_t, false>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((dcn_taps_kernel<f16_t, f16_t, false>), grid, block, 0, s, a);
+    return ganet_check_launch();
+  }
   if (pl.ta == GANET_F32 && pl.fsplit)
     launch_main<float, float, true>(pl, a, s);
   else if (pl.ta == GANET_F32)
@@ -1007,3 +1383,11 @@ extern "C" int ganet_deform_conv_forward(const void *x, const float *offset,
     launch_main<f16_t, f16_t>(pl, a, s);
   return ganet_check_launch();
 }
+
+#ifdef GANET_TAPS_STAMPS
+extern "C" int ganet_debug_taps_stamps(long long *host48) {
+  return hipMemcpyFromSymbol(host48, HIP_SYMBOL(g_taps_stamps), 48 * sizeof(long long)) == hipSuccess
+             ? GANET_OK
+             : GANET_ERR_HIP;
+}
+#endif

@@ -99,6 +99,8 @@ def deform_conv_forward(input, offset, weight, stride=(1, 1), padding=(0, 0),
                         keep_y=None):
     """Raw forward on the HIP library.  `input` NCHW (contiguous or
     channels_last) on a GPU; returns a tensor of the same memory format.
+    algo: ganet_dcn_params.algo (0 = the library chooses: 5 for calls of one round of
+    workgroups such as batch 1, 2 where contract-then-sample applies, else 1).
     keep_y: a dict; where the library can keep the per-tap products of the whole batch
     (GANET_DCN_ALGO_KEEP_Y) it gets keep_y["y"] = that float32 tensor (a view of the call's
     workspace) for deform_conv_backward(..., y_saved=...), otherwise it stays empty.

@@ -118,7 +118,16 @@ typedef struct {
                                tap into a three-plane ring that is overwritten in
                                place; 16-bit arithmetic, Cin 64/128/256, Cout <= 64,
                                "same" output size, <= 16 taps, H*W <= 4096; needs
-                               the 8 x 32-CU layout of MI355X).
+                               the 8 x 32-CU layout of MI355X);
+                               5 = small batches (the reference's speed test runs
+                               batch 1, tools/ganet/speed_test.py:57-65): ONE launch in
+                               which a workgroup owns 16 output pixels x 64 outputs and
+                               its wavefronts split the taps; sample-then-contract like
+                               1, partial sums added in a fixed order.  One deformable
+                               group; float32 tensors with mfma_bf16 0 or 1.  Chosen
+                               automatically while a call is one round of workgroups
+                               (B*Hout*Wout/16 * ceil(Cout/64) <= 256; process-wide
+                               knob GANET_TAPS_MAX_TILES, 0 = never).
                                | GANET_DCN_ALGO_KEEP_Y: training - see below */
   int32_t debug;            /* must be 0 (ablation bits of profiling builds) */
 } ganet_dcn_params;
@@ -151,7 +160,7 @@ int ganet_dcn_out_size(int in, int pad, int dilation, int k, int stride);
  * Returns 0 for invalid parameters. */
 size_t ganet_deform_conv_workspace_bytes(const ganet_dcn_params *p);
 
-/* Which algorithm ganet_deform_conv_forward runs for `p`: 1, 2, 3 or 4 as in
+/* Which algorithm ganet_deform_conv_forward runs for `p`: 1, 2, 3, 4 or 5 as in
  * ganet_dcn_params.algo (0 for invalid parameters).  No counterpart in the
  * reference; for logs and benchmarks. */
 int ganet_deform_conv_algorithm(const ganet_dcn_params *p);
@@ -170,7 +179,11 @@ size_t ganet_deform_conv_y_offset(const ganet_dcn_params *p);
 
 /* Weight pre-packing (no counterpart in the reference, which hands the raw
  * [Cout,Cin,kH,kW] tensor to cuBLAS on every call, deform_conv_cuda.cpp:228-236):
- * the kernels read weights as [tap][Cout][Cin] in their arithmetic dtype.
+ * the kernels read weights as [tap][Cout][Cin] in their arithmetic dtype (float32 tensors
+ * in the default arithmetic: a hi and a lo bf16 plane).  16-bit planes are followed by a
+ * second, fragment-major copy of the same values (blocks of 16 outputs x 32 channels in
+ * MFMA operand order) that algorithm 5 reads; both are written whatever the batch size of
+ * `p`, so a buffer packed for a shape serves it at every batch size.
  * ganet_deform_conv_forward packs into its workspace on every call unless
  * p->weight_is_packed is set and `weight` points at a buffer filled here. */
 size_t ganet_deform_conv_packed_weight_bytes(const ganet_dcn_params *p);

@@ -126,6 +126,35 @@ def test_algorithm_choice_is_host_logic():
     assert L.ganet_deform_conv_backward_workspace_bytes(ctypes.byref(strided)) == 0
 
 
+def test_small_batch_choice_is_host_logic():
+    """Algorithm 5 (taps on different wavefronts) is what one round of workgroups gets - C1's
+    batch 1 in bf16 and float32 - and nothing larger; it needs one deformable group and 16-bit
+    MFMA operands; the packed weights have one size at every batch size (they carry the
+    fragment-major copy whether or not this batch reads it); the kept-Y bit rules it out."""
+    L = _lib.lib()
+    lfa = dict(Cin=256, H=40, W=100, Cout=64, x_layout=1, out_layout=1)
+    for dt in (_lib.GANET_BF16, _lib.GANET_F16, _lib.GANET_F32):
+        assert L.ganet_deform_conv_algorithm(ctypes.byref(_dcn_params(B=1, dtype=dt, **lfa))) == 5
+        assert L.ganet_deform_conv_algorithm(ctypes.byref(_dcn_params(B=2, dtype=dt, **lfa))) == 2
+        sizes = {L.ganet_deform_conv_packed_weight_bytes(ctypes.byref(_dcn_params(B=b, dtype=dt, **lfa)))
+                 for b in (1, 2, 128)}
+        assert len(sizes) == 1 and 0 not in sizes
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(_dcn_params(B=1, mfma_bf16=1, **lfa))) == 5
+    # exact float32 cannot run there; an explicit 5 is refused, the automatic choice moves on
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(_dcn_params(B=1, mfma_bf16=2, **lfa))) in (1, 2)
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(_dcn_params(B=1, mfma_bf16=2, algo=5, **lfa))) == 0
+    assert L.ganet_deform_conv_algorithm(
+        ctypes.byref(_dcn_params(B=1, deformable_groups=2, algo=5, **lfa))) == 0
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(_dcn_params(B=1, deformable_groups=2, **lfa))) == 1
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(_dcn_params(B=128, algo=5, **lfa))) == 5   # on request
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(_dcn_params(B=1, algo=6, **lfa))) == 0
+    keep = _dcn_params(B=1, algo=_lib.GANET_DCN_ALGO_KEEP_Y, **lfa)
+    assert L.ganet_deform_conv_algorithm(ctypes.byref(keep)) == 2
+    # two output blocks double the tiles: 250 pixel tiles x 2 is more than one round
+    assert L.ganet_deform_conv_algorithm(
+        ctypes.byref(_dcn_params(B=1, dtype=_lib.GANET_BF16, **dict(lfa, Cout=128)))) == 2
+
+
 def test_algo_bits_are_host_logic():
     """GANET_DCN_ALGO_KEEP_Y / GANET_DCN_BWD_OVERWRITE_X ride on `algo`: where the per-tap
     products can be kept the workspace grows to the whole batch's Y and the offset is

@@ -57,20 +57,24 @@ GENERIC = [
 ]
 
 
+# algo 0: what the library picks (these small shapes are one round of workgroups: algorithm 5
+# where there is one deformable group); algo 1: the fused kernel, the general-purpose path
 @pytest.mark.parametrize("case", GENERIC)
 @pytest.mark.parametrize("channels_last", [False, True])
-def test_fp32_generic_shapes(case, channels_last):
+@pytest.mark.parametrize("algo", [0, 1])
+def test_fp32_generic_shapes(case, channels_last, algo):
     B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
     x, off, w = make(*case)
     ref = O.deform_conv_forward(x, off, w, st, pad, dil, 1, dg)
-    got = run_gpu(x, off, w, st, pad, dil, dg, channels_last=channels_last)
+    got = run_gpu(x, off, w, st, pad, dil, dg, channels_last=channels_last, algo=algo)
     assert got.shape == ref.shape
     assert rel_err(got, ref) <= TOL_F32
 
 
 @pytest.mark.parametrize("case", GENERIC[:4])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_16bit_generic_shapes(case, dtype):
+@pytest.mark.parametrize("algo", [0, 1])
+def test_16bit_generic_shapes(case, dtype, algo):
     B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
     x, off, w = make(*case)
     # the oracle sees the same rounded inputs the kernel reads
@@ -78,7 +82,7 @@ def test_16bit_generic_shapes(case, dtype):
     wr = torch.from_numpy(w).to(dtype).float().numpy()
     ref = O.deform_conv_forward(xr, off, wr, st, pad, dil, 1, dg)
     for cl in (False, True):
-        got = run_gpu(x, off, w, st, pad, dil, dg, dtype=dtype, channels_last=cl)
+        got = run_gpu(x, off, w, st, pad, dil, dg, dtype=dtype, channels_last=cl, algo=algo)
         assert rel_err(got, ref) <= TOL_16
 
 
@@ -176,7 +180,7 @@ def test_fp32_modes_split_exact_bf16(case):
     x *= np.exp(rng.uniform(-6, 6, (B, 1, H, W))).astype(np.float32)   # per-pixel scales e^-6..e^6
     ref = O.deform_conv_forward(x, off, w, st, pad, dil, 1, dg, acc64=True, nthreads=4)
     errs = {}
-    for mode, algo in ((False, 0), (False, 2), ("exact", 0), ("exact", 2)):
+    for mode, algo in ((False, 0), (False, 2), (False, 5), ("exact", 0), ("exact", 2)):
         for cl in (False, True):
             got = run_gpu(x, off, w, st, pad, dil, dg, channels_last=cl, mfma_bf16=mode,
                           algo=algo)

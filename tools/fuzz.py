@@ -76,7 +76,7 @@ def fuzz_forward(rng, n):
         dtype = [torch.float32, torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 4))]
         nhwc = rng.random() < 0.5
         relu = rng.random() < 0.3
-        algo = int(rng.choice([0, 0, 0, 1, 2]))
+        algo = int(rng.choice([0, 0, 0, 1, 2, 5]))
         x, off, w, mask, bias, Ho, Wo = tensors(rng, c, modulated)
         if Ho < 1 or Wo < 1:
             continue
@@ -95,7 +95,8 @@ def fuzz_forward(rng, n):
         except _lib.GanetError as e:
             if e.status == _lib.GANET_ERR_UNSUPPORTED and (algo == 2 or c["dg"] > 1):
                 unsupported += 1
-                k = "algo 2 forced" if algo == 2 else "deformable groups %d" % c["dg"]
+                k = "algo 2 forced" if algo == 2 else "deformable groups %d%s" % (
+                    c["dg"], " (algo 5 forced)" if algo == 5 else "")
                 why[k] = why.get(k, 0) + 1
                 continue
             print("FAIL (status %d) %s" % (e.status, tag))
@@ -273,7 +274,7 @@ def fuzz_lfa(rng, n):
         K = int(rng.choice([5, 7, 9]))
         H, W, B = int(rng.integers(1, 48)), int(rng.integers(K, 110)), int(rng.integers(1, 40))   # W >= K: the reference refuses narrower maps
         dtype = [torch.float32, torch.bfloat16, torch.bfloat16, torch.float16][int(rng.integers(0, 4))]
-        algos = [0, 1] + ([2] if 2 * Cout <= Cin else []) + \
+        algos = [0, 1, 5] + ([2] if 2 * Cout <= Cin else []) + \
             ([3] if 2 * Cout <= Cin and Cout == 64 and dtype != torch.float32 else []) + \
             ([4] if 2 * Cout <= Cin and Cout == 64 and dtype != torch.float32 and H * W <= 4096 else [])
         algo = int(rng.choice(algos))
