@@ -19,8 +19,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LFA_KERNELS = ("dcn_fused_kernel", "cts_gemm", "cts_sample_kernel", "lfa_stream_kernel",
-               "lfa_ring_kernel")
+LFA_KERNELS = ("dcn_fused_kernel", "dcn_taps_kernel", "cts_gemm", "cts_sample_kernel",
+               "lfa_stream_kernel", "lfa_ring_kernel")
 KERNEL_SOURCES = ("deform_conv.hip", "deform_conv_cts.hip", "deform_conv_stream.hip",
                   "deform_conv_ring.hip", "dcn_device.h")
 
