@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 OUT=${TMPDIR:-/tmp}/ganet_asan
 mkdir -p $OUT
-SRC="api decode deform_conv deform_conv_cts deform_conv_stream deform_conv_bwd lane_format"
+SRC="api decode deform_conv deform_conv_cts deform_conv_stream deform_conv_ring deform_conv_bwd lane_format"
 OBJS=""
 for s in $SRC; do
   /opt/rocm/bin/hipcc -O1 -g --offload-arch=gfx950 -std=c++17 -Iinclude -Iganet_amd/csrc -ffp-contract=off \

@@ -36,8 +36,8 @@ int main() {
       p.out_layout = (int32_t)(rng() % 2);
       p.mfma_bf16 = (int32_t)(rng() % 3);
       p.fuse_relu = p.offset_is_points = p.weight_is_packed = p.debug = 0;
-      static const int32_t algos[] = {0, 1, 2, 3, 0x100, 0x102, 0x200, 0x300, 0x400};
-      p.algo = algos[rng() % 9];
+      static const int32_t algos[] = {0, 1, 2, 3, 4, 5, 6, 0x100, 0x102, 0x105, 0x200, 0x300, 0x400};
+      p.algo = algos[rng() % 13];
       p.groups = (int32_t)(rng() % 3) + 1;
       p.deformable_groups = (int32_t)(rng() % 3) + 1;
     }
