@@ -397,6 +397,37 @@ __global__ __launch_bounds__(256) void bwd_unpack_add_weight_kernel(
   }
 }
 
+// gw[Cout][Cin/groups][T] += sum over planes of part[plane][T*Cout][Cp], planes added in
+// order.  Threads walk the planes' own layout, so the reads are coalesced; the one write per
+// element is the scattered side.
+template <typename TD>
+__global__ __launch_bounds__(256) void bwd_reduce_unpack_weight_kernel(
+    const float *__restrict__ part, int planes, TD *__restrict__ gw, int Cout, int Cin, int T,
+    int Cp, int groups) {
+  const int cig = Cin / groups, cog = Cout / groups;
+  const long long total = (long long)T * Cout * Cp;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total;
+       k += (long long)gridDim.x * 256) {
+    const int cc = (int)(k % Cp);
+    const int n = (int)(k / Cp);
+    const int o = n % Cout, t = n / Cout;
+    const int cg = cc - (o / cog) * cig;
+    if (cc >= Cin || cg < 0 || cg >= cig) continue;
+    float sum = 0.f;
+    int pn = 0;
+    for (; pn + 8 <= planes; pn += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(pn + j) * total + k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[j];
+    }
+    for (; pn < planes; ++pn) sum += part[(size_t)pn * total + k];
+    const size_t dst = ((size_t)o * cig + cg) * T + t;
+    gw[dst] = from_f32<TD>(to_f32(gw[dst]) + sum);
+  }
+}
+
 // ===== commuted form: scatter / gather Cout-wide rows of the per-tap products ===========
 // With Y_t = X * W_t^T (the forward's contract-then-sample intermediate) the backward is
 //   grad_Y_t[q][o] += bilinear weight * mask * grad_out[p][o]        (scatter, atomics)
@@ -857,14 +888,15 @@ __global__ __launch_bounds__(256) void cts_bwd_wgrad_kernel(const float *__restr
 // (whole 16-byte loads, a pixel row contiguous across lanes), split them, and park them in
 // LDS pixel-major per column ([plane][k half][column][8 pixels] bf16: the 16 bytes a lane
 // reads are one MFMA operand, 32 lanes read 512 contiguous bytes); two buffers, one barrier
-// per step.  One atomic flush of 128-byte runs at the end.
+// per step.  At the end the accumulators go to the share's own plane of partial sums (128-byte
+// runs; `part`), or, without one, into gw through atomics.
 constexpr int WG_WAVES = 8;
 constexpr int WG_KS = 16;
 
 template <int NTW, int NH>
 __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
     const float *__restrict__ gy, const float *__restrict__ x, float *__restrict__ gw,
-    long long M, int N, int Cp) {
+    long long M, int N, int Cp, float *__restrict__ part, int first) {
   constexpr int BN = NH * NTW * 32;
   constexpr int CT = WG_WAVES / NH;             // c tiles of 32 per workgroup
   constexpr int WG_BC = CT * 32;
@@ -887,7 +919,10 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
   const long long per = (nks + gridDim.y - 1) / gridDim.y;
   const long long ks_beg = (long long)blockIdx.y * per;
   const long long ks_end = ks_beg + per < nks ? ks_beg + per : nks;
-  if (ks_beg >= ks_end) return;                 // the whole workgroup leaves together
+  // no pixels for this share: the whole workgroup leaves together - unless its plane of partial
+  // sums has never been written, then it writes the zeros it holds
+  const bool idle = ks_beg >= ks_end;
+  if (idle && !(part && first)) return;
 
   // fetch task: pixel octet po of the step, column quad cq (gy columns first, then x)
   const bool fetcher = tid < 2 * NQ;
@@ -940,7 +975,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  if (fetcher) {
+  if (fetcher && !idle) {
     fetch(raw, ks_beg);
     park(0);
     if (ks_beg + 1 < ks_end) fetch(raw, ks_beg + 1);
@@ -973,7 +1008,22 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
   }
 
   // lane (i, h), register r of tile t: row (r & 3) + 8 (r >> 2) + 4 h, column i
-  float *out = gw + (size_t)(nb0 + nh * NTW * 32 + 4 * h) * Cp + cb0 + ct * 32 + i;
+  const size_t at = (size_t)(nb0 + nh * NTW * 32 + 4 * h) * Cp + cb0 + ct * 32 + i;
+  if (part) {
+    // this share's own plane: plain stores (the first chunk of a call) or load-add-store
+    // (later chunks; the launches of a call are ordered on its stream and a plane has one
+    // owner per launch), summed in plane order by bwd_reduce_unpack_weight_kernel
+    float *out = part + (size_t)blockIdx.y * N * Cp + at;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float *dst = out + (size_t)(t * 32 + (r & 3) + 8 * (r >> 2)) * Cp;
+        *dst = first ? acc[t][r] : *dst + acc[t][r];
+      }
+    return;
+  }
+  float *out = gw + at;
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -983,33 +1033,52 @@ __global__ __launch_bounds__(WG_WAVES * 64) void cts_bwd_wgrad_split_kernel(
 
 // Launches the split kernel where its tiling fits (N a multiple of 64 * NTW for an
 // instantiated NTW, Cp a multiple of 128); false = use cts_bwd_wgrad_kernel.
-bool launch_wgrad_split(const float *gy, const float *x, float *gw, long long M, int N, int Cp,
-                        hipStream_t s) {
+struct WgradGeometry {
+  bool tall;
+  int ntw, gx;
+  long long split;   // shares of the pixels = planes of partial sums
+};
+
+// false = the split kernel's tiling does not fit (use cts_bwd_wgrad_kernel)
+bool wgrad_split_geometry(long long M, int N, int Cp, WgradGeometry *g) {
   if (getenv("GANET_BWD_WGRAD_F32")) return false;   // A/B knob
   if (N % 64 || Cp % 128 || M < 1) return false;
   // tall tiles (NH = 1: NTW*32 rows x 256 columns) where gy is the wider matrix and the shape
   // allows: gy is then read once per 256 columns of x instead of once per 128
-  const bool tall = Cp % 256 == 0 && N >= Cp && !getenv("GANET_BWD_WGRAD_WIDE");
-  const int m = tall ? N / 32 : N / 64;           // row blocks of 32 (tall) or 64 (two halves)
-  int ntw = 0;
+  g->tall = Cp % 256 == 0 && N >= Cp && !getenv("GANET_BWD_WGRAD_WIDE");
+  const int m = g->tall ? N / 32 : N / 64;        // row blocks of 32 (tall) or 64 (two halves)
+  g->ntw = 0;
   for (int cand : {7, 9, 5, 4, 3, 2, 1})
     if (m % cand == 0) {
-      ntw = cand;
+      g->ntw = cand;
       break;
     }
-  if (!ntw) return false;
-  const int gx = (m / ntw) * (Cp / (tall ? 256 : 128));
+  if (!g->ntw) return false;
+  g->gx = (m / g->ntw) * (Cp / (g->tall ? 256 : 128));
   const long long nks = (M + WG_KS - 1) / WG_KS;
-  long long split = 256 / gx;                       // one workgroup per CU
-  if (split > nks / 8) split = nks / 8;             // >= 8 steps between flushes
-  if (split < 1) split = 1;
+  g->split = 256 / g->gx;                           // one workgroup per CU
+  if (g->split > nks / 8) g->split = nks / 8;       // >= 8 steps between flushes
+  if (g->split < 1) g->split = 1;
+  return true;
+}
+
+// part: planes of partial sums ([split][N][Cp], `first` = not written yet in this call), or
+// nullptr = add into gw through atomics.  *planes = the shares of this launch.
+bool launch_wgrad_split(const float *gy, const float *x, float *gw, long long M, int N, int Cp,
+                        float *part, int first, long long *planes, hipStream_t s) {
+  WgradGeometry g;
+  if (!wgrad_split_geometry(M, N, Cp, &g)) return false;
+  const bool tall = g.tall;
+  const int ntw = g.ntw, gx = g.gx;
+  const long long split = g.split;
+  if (planes) *planes = split;
   const dim3 grid((unsigned)gx, (unsigned)split), block(WG_WAVES * 64);
 #define GANET_WGRAD_CASE(n)                                                                       \
   case n:                                                                                         \
     if (tall)                                                                                     \
-      hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<n, 1>), grid, block, 0, s, gy, x, gw, M, N, Cp); \
+      hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<n, 1>), grid, block, 0, s, gy, x, gw, M, N, Cp, part, first); \
     else                                                                                          \
-      hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<n, 2>), grid, block, 0, s, gy, x, gw, M, N, Cp); \
+      hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<n, 2>), grid, block, 0, s, gy, x, gw, M, N, Cp, part, first); \
     break;
   switch (ntw) {
     GANET_WGRAD_CASE(1)
@@ -1020,9 +1089,9 @@ bool launch_wgrad_split(const float *gy, const float *x, float *gw, long long M,
     GANET_WGRAD_CASE(7)
     default:
       if (tall)
-        hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<9, 1>), grid, block, 0, s, gy, x, gw, M, N, Cp);
+        hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<9, 1>), grid, block, 0, s, gy, x, gw, M, N, Cp, part, first);
       else
-        hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<9, 2>), grid, block, 0, s, gy, x, gw, M, N, Cp);
+        hipLaunchKernelGGL((cts_bwd_wgrad_split_kernel<9, 2>), grid, block, 0, s, gy, x, gw, M, N, Cp, part, first);
       break;
   }
 #undef GANET_WGRAD_CASE
@@ -1069,11 +1138,12 @@ struct BwdPlan {
   bool commuted;
   int nb;                 // images per chunk
   size_t y_bytes, gy_bytes, gxc_bytes, wqt_bytes, wsp_bytes, geo_bytes;
+  size_t wpart_bytes;   // the split weight-gradient kernel's planes of partial sums
   size_t gb_bytes;   // float32 bias gradient of a 16-bit call
   bool overwrite_x;  // GANET_DCN_BWD_OVERWRITE_X: grad_x is written, not added into
   size_t total() const {
     return xh_bytes + gxh_bytes + go_bytes + wp_bytes + gwp_bytes + y_bytes + gy_bytes +
-           gxc_bytes + wqt_bytes + wsp_bytes + geo_bytes + gb_bytes;
+           gxc_bytes + wqt_bytes + wsp_bytes + geo_bytes + wpart_bytes + gb_bytes;
   }
 };
 
@@ -1134,6 +1204,7 @@ int make_bwd_plan(const ganet_dcn_params *p_in, BwdPlan *pl) {
   pl->commuted = can && (p->algo == 2 || (p->algo == 0 && 2 * p->Cout <= pl->Cp));
   pl->nb = 0;
   pl->y_bytes = pl->gy_bytes = pl->gxc_bytes = pl->wqt_bytes = pl->wsp_bytes = pl->geo_bytes = 0;
+  pl->wpart_bytes = 0;
   if (pl->commuted) {
     const size_t N = (size_t)pl->T * p->Cout;
     const size_t per_img = (size_t)p->H * p->W * N * 4;
@@ -1162,6 +1233,13 @@ int make_bwd_plan(const ganet_dcn_params *p_in, BwdPlan *pl) {
                     ganet_align_up(nb * (size_t)pl->T * pl->Ho * pl->Wo * 8, 256);
     // grad_x is built per chunk in gxc and added to the caller's tensor: no full-size copy
     pl->gxh_bytes = 0;
+    // the weight-gradient GEMM's partial sums: one [N][Cp] plane per share of the pixels (the
+    // first chunk is the largest, so it has the most shares); GANET_BWD_WGRAD_ATOMIC=1 keeps
+    // the atomic flush into one plane (A/B knob, read per call like the other backward knobs)
+    WgradGeometry g;
+    if (!getenv("GANET_BWD_WGRAD_ATOMIC") &&
+        wgrad_split_geometry((long long)nb * p->H * p->W, (int)N, pl->Cp, &g))
+      pl->wpart_bytes = ganet_align_up((size_t)g.split * N * pl->Cp * 4, 256);
   }
   return GANET_OK;
 }
@@ -1306,6 +1384,8 @@ int backward_impl(const void *x, const float *offset, const float *mask, const v
     unsigned short *wsp = reinterpret_cast<unsigned short *>(cw + pl.y_bytes + pl.gy_bytes +
                                                              pl.gxc_bytes + pl.wqt_bytes);
     unsigned char *geo = cw + pl.y_bytes + pl.gy_bytes + pl.gxc_bytes + pl.wqt_bytes + pl.wsp_bytes;
+    float *wpart = pl.wpart_bytes ? reinterpret_cast<float *>(geo + pl.geo_bytes) : nullptr;
+    long long wplanes = 0;   // planes of partial sums the first chunk wrote
     const int N = T * p->Cout;
     if (need_in) {
       GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(bwd_weight_views_kernel<TIO>,
@@ -1318,7 +1398,7 @@ int backward_impl(const void *x, const float *offset, const float *mask, const v
       if (grad_mask && hipMemsetAsync(grad_mask, 0, off_elems * 2, s) != hipSuccess)
         return GANET_ERR_HIP;
     }
-    if (grad_weight && hipMemsetAsync(gwp, 0, pl.gwp_bytes, s) != hipSuccess) return GANET_ERR_HIP;
+    if (grad_weight && !wpart && hipMemsetAsync(gwp, 0, pl.gwp_bytes, s) != hipSuccess) return GANET_ERR_HIP;
     for (int img0 = 0; img0 < p->B; img0 += pl.nb) {
       const int nimg = p->B - img0 < pl.nb ? p->B - img0 : pl.nb;
       const long long M = (long long)nimg * HW;
@@ -1410,8 +1490,11 @@ int backward_impl(const void *x, const float *offset, const float *mask, const v
         }
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
       }
-      if (grad_weight && launch_wgrad_split(gyb, xc, gwp, M, N, pl.Cp, s)) {
+      long long planes_now = 0;
+      if (grad_weight && launch_wgrad_split(gyb, xc, gwp, M, N, pl.Cp, wpart, img0 == 0, &planes_now, s)) {
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+        if (img0 == 0) wplanes = planes_now;
+        else if (wpart && planes_now > wplanes) return GANET_ERR_HIP;   // cannot happen: chunks never grow
       } else if (grad_weight) {
         const int nblocks = (N / 64) * (pl.Cp / 64);
         long long split = 1024 / nblocks + 1;
@@ -1423,7 +1506,14 @@ int backward_impl(const void *x, const float *offset, const float *mask, const v
         if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
       }
     }
-    if (grad_weight) {
+    if (grad_weight && wpart) {
+      GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(
+                                bwd_reduce_unpack_weight_kernel<TIO>,
+                                dim3(blocks_for((long long)N * pl.Cp)), dim3(256), 0, s, wpart,
+                                (int)wplanes, static_cast<TIO *>(grad_weight), p->Cout, p->Cin, T,
+                                pl.Cp, p->groups));
+      if (ganet_check_launch() != GANET_OK) return GANET_ERR_HIP;
+    } else if (grad_weight) {
       GANET_IO_DISPATCH(dt, hipLaunchKernelGGL(
                                 bwd_unpack_add_weight_kernel<TIO>,
                                 dim3(blocks_for((long long)p->Cout * p->Cin * T)), dim3(256), 0, s,

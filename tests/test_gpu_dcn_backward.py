@@ -156,6 +156,32 @@ def test_commuted_form_walks_the_batch_in_chunks(monkeypatch):
     close(gw, ref["grad_weight"], "grad_weight")
 
 
+def test_weight_gradient_planes_chunks_and_atomic_flush_agree(monkeypatch):
+    """The split weight-gradient kernel leaves its accumulators in planes of partial sums that a
+    second kernel adds in plane order; with several chunks the later ones add into the planes;
+    GANET_BWD_WGRAD_ATOMIC=1 (the A/B knob) keeps the atomic flush.  All three agree with the
+    oracle and with one another to rounding (grad_Y's LDS bins add in arrival order, so not
+    even two runs of one path are bit-identical)."""
+    case = COMMUTED[0]
+    B, Cin, H, W, Cout, kH, kW, st, pad, dil, dg = case
+    x, off, w, _, go = make(case, 37, False)
+    ref = O.deform_conv_backward(x, off, w, go, st, pad, dil, 1, dg)["grad_weight"]
+    dev = torch.device("cuda", 0)
+    tx, toff, tw, tgo = (torch.from_numpy(a).to(dev) for a in (x, off, w, go))
+
+    def gw():
+        return dcn.deform_conv_backward(tx, toff, tw, tgo, st, pad, dil, 1, dg, algo=2,
+                                        need_input=False)[3]
+
+    whole = gw()
+    close(whole, ref, "grad_weight, planes")
+    monkeypatch.setenv("GANET_BWD_BUDGET_MB", "1")       # two chunks: the second adds into the planes
+    close(gw(), ref, "grad_weight, planes, two chunks")
+    monkeypatch.delenv("GANET_BWD_BUDGET_MB")
+    monkeypatch.setenv("GANET_BWD_WGRAD_ATOMIC", "1")
+    close(gw(), ref, "grad_weight, atomic flush")
+
+
 def test_commuted_form_on_a_large_map():
     """80x200 (the C4 feature map): 125 tiles of 128 pixels per image and tap in the binned
     grad_Y kernel, several 16-pixel steps per share in the weight-gradient kernel."""
