@@ -378,7 +378,9 @@ def test_non_finite_inputs_on_the_split_fp32_path():
 @pytest.mark.parametrize("dtype,algo,Cin,mode", [
     (torch.float32, 1, 64, None), (torch.float32, 1, 256, None), (torch.float32, 1, 64, "exact"),
     (torch.bfloat16, 1, 256, None), (torch.float16, 1, 128, None),
-    (torch.bfloat16, 2, 256, None), (torch.float32, 2, 256, None), (torch.float16, 2, 128, None)])
+    (torch.bfloat16, 2, 256, None), (torch.float32, 2, 256, None), (torch.float16, 2, 128, None),
+    (torch.float32, 5, 64, None), (torch.float32, 5, 256, None), (torch.bfloat16, 5, 256, None),
+    (torch.float16, 5, 128, None)])
 def test_repeated_launches_are_bit_identical(dtype, algo, Cin, mode):
     """The same launch five times over at a size where two wavefronts share a SIMD (40 images of
     34x106): every result must equal the first bit for bit.  A data hazard that shows only now
