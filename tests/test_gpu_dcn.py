@@ -226,13 +226,14 @@ def test_modulated_with_bias_and_relu():
     assert rel_err(got_relu, np.maximum(ref, 0)) <= TOL_F32
 
 
-def test_known_answers_on_gpu():
+@pytest.mark.parametrize("algo", [0, 1, 5])   # 0 is algorithm 5 at these sizes; 1 = the fused kernel
+def test_known_answers_on_gpu(algo):
     # zero offsets == plain convolution
     rng = np.random.default_rng(3)
     x = rng.standard_normal((2, 64, 10, 16)).astype(np.float32)
     w = (rng.standard_normal((64, 64, 1, 7)) / 20).astype(np.float32)
     off = np.zeros((2, 14, 10, 16), np.float32)
-    got = run_gpu(x, off, w, (1, 1), (0, 3), (1, 1))
+    got = run_gpu(x, off, w, (1, 1), (0, 3), (1, 1), algo=algo)
     ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(),
                                      torch.from_numpy(w).double(), padding=(0, 3)).numpy()
     assert rel_err(got, ref) <= TOL_F32
@@ -246,7 +247,7 @@ def test_known_answers_on_gpu():
     off[0, 1, 2, 0] = -1.0
     off[0, 1, 3, 7] = 1.0
     off[0, 0, 1, 3] = -1.5
-    got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1))[0, 0]
+    got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1), algo=algo)[0, 0]
     assert np.all(got[0] == 0) and np.all(got[5] == 0)
     assert got[2, 0] == 0 and got[3, 7] == 0 and got[1, 3] == 0.5 and got[4, 4] == 1.0
     # an inf pixel reaches only the outputs whose support holds it
@@ -255,9 +256,10 @@ def test_known_answers_on_gpu():
     off = np.zeros((1, 2, 6, 8), np.float32)
     # (exact float32 arithmetic reads +inf like the reference; the default three-pass form reads NaN
     # there - x = hi + lo with lo = inf - inf - and is finite everywhere else: INTEGRATION.md)
-    got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1), mfma_bf16="exact")[0, 0]
-    assert np.isinf(got[0, 0]) and np.isfinite(got[0, 1:]).all() and np.isfinite(got[1:]).all()
-    got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1))[0, 0]
+    if algo != 5:   # (algorithm 5 has no exact-float32 form)
+        got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1), mfma_bf16="exact", algo=algo)[0, 0]
+        assert np.isinf(got[0, 0]) and np.isfinite(got[0, 1:]).all() and np.isfinite(got[1:]).all()
+    got = run_gpu(x, off, w, (1, 1), (0, 0), (1, 1), algo=algo)[0, 0]
     assert not np.isfinite(got[0, 0]) and np.isfinite(got[0, 1:]).all() and np.isfinite(got[1:]).all()
 
 
@@ -363,6 +365,12 @@ def test_non_finite_inputs_on_the_split_fp32_path():
     bad = ~np.isfinite(ref)
     assert bad.any() and (~bad).any()
     p = dict(ref=ref)
+    # the default mode on every algorithm that has it (these sizes give 5 when left to the
+    # library; 2 is the three-pass GEMM the docstring speaks of, 1 the fused kernel)
+    for algo in (1, 2, 5):
+        got = run_gpu(x, off, w, (1, 1), (0, 3), (1, 1), mfma_bf16=False, algo=algo)
+        assert np.array_equal(~np.isfinite(got), bad), algo
+        assert np.abs(got[~bad] - ref[~bad]).max() <= TOL_F32 * np.abs(ref[~bad]).max(), algo
     for mode in ("exact", False):
         got = run_gpu(x, off, w, (1, 1), (0, 3), (1, 1), mfma_bf16=mode)
         assert np.array_equal(~np.isfinite(got), bad), mode
